@@ -1,0 +1,100 @@
+"""ctypes bindings for the CPU checkers.  TEST INFRASTRUCTURE ONLY.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline
+leg.  The product package (visual-slam_amd/) never imports this.
+
+  port()  -> oracle/libvsm_oracle.so   C restatement (oracle/vsm_oracle.c)
+  ref()   -> oracle/_ref/libvsm_ref.so the real reference function compiled
+             from /root/reference/include/visnav/keypoints.h:247-361, or None
+             when it has not been built.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _as_desc(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim != 2 or a.shape[1] != 4:
+        a = a.reshape(-1, 4)
+    return a
+
+
+class _Matcher:
+    def __init__(self, lib, prefix, kind):
+        self.kind = kind
+        self._lib = lib
+        self._match = getattr(lib, prefix + "_match")
+        self._match.restype = C.c_size_t
+        self._match.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, C.c_int,
+                                C.c_double, _i32p, C.c_size_t]
+        self._match_db = getattr(lib, prefix + "_match_db_pair")
+        self._match_db.restype = C.c_size_t
+        self._match_db.argtypes = [_u64p, _u32p, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_double, _i32p, C.c_size_t]
+        self._nn2 = None
+        if hasattr(lib, prefix + "_nn2"):
+            self._nn2 = getattr(lib, prefix + "_nn2")
+            self._nn2.restype = None
+            self._nn2.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _i32p, _i32p, _i32p]
+
+    def match(self, d1, d2, threshold=70, dist_2_best=1.2) -> np.ndarray:
+        """visnav::matchDescriptors -> int32[n_matches, 2] in reference order."""
+        d1, d2 = _as_desc(d1), _as_desc(d2)
+        cap = max(1, min(len(d1), len(d2)))
+        out = np.empty((cap, 2), dtype=np.int32)
+        n = self._match(d1.ctypes.data_as(_u64p), len(d1), d2.ctypes.data_as(_u64p),
+                        len(d2), int(threshold), float(dist_2_best),
+                        out.ctypes.data_as(_i32p), cap)
+        if n == C.c_size_t(-1).value:
+            raise MemoryError("oracle allocation failed")
+        assert n <= cap, (n, cap)
+        return out[:n].copy()
+
+    def match_db_pair(self, db, offsets, i1, i2, threshold, dist_2_best, out) -> int:
+        """One pair of a database; `out` is a caller-owned int32[cap, 2] buffer
+        (so a thread pool can call this without allocating)."""
+        return self._match_db(db.ctypes.data_as(_u64p), offsets.ctypes.data_as(_u32p),
+                              int(i1), int(i2), int(threshold), float(dist_2_best),
+                              out.ctypes.data_as(_i32p), out.shape[0])
+
+    def nn2(self, q, t):
+        """(best_idx, best_dist, second_dist) int32[nq] each (port only)."""
+        if self._nn2 is None:
+            raise NotImplementedError("nn2 is only restated in the C port")
+        q, t = _as_desc(q), _as_desc(t)
+        bi = np.empty(len(q), dtype=np.int32)
+        bd = np.empty(len(q), dtype=np.int32)
+        sd = np.empty(len(q), dtype=np.int32)
+        self._nn2(q.ctypes.data_as(_u64p), len(q), t.ctypes.data_as(_u64p), len(t),
+                  bi.ctypes.data_as(_i32p), bd.ctypes.data_as(_i32p),
+                  sd.ctypes.data_as(_i32p))
+        return bi, bd, sd
+
+
+_cache = {}
+
+
+def port() -> _Matcher:
+    if "port" not in _cache:
+        path = os.path.join(_HERE, "libvsm_oracle.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: run `make -C oracle port`")
+        _cache["port"] = _Matcher(C.CDLL(path), "vsm_oracle", "port")
+    return _cache["port"]
+
+
+def ref():
+    if "ref" not in _cache:
+        path = os.path.join(_HERE, "_ref", "libvsm_ref.so")
+        _cache["ref"] = _Matcher(C.CDLL(path), "vsm_ref", "reference") \
+            if os.path.exists(path) else None
+    return _cache["ref"]

@@ -1,0 +1,157 @@
+"""Deterministic synthetic ORB-like descriptor sets.
+
+Uniform-random 256-bit descriptors give *zero* matches at the reference's
+default threshold 70 (the minimum of ~2000 Binomial(256, 1/2) draws is ~100),
+so every set made here carries planted structure: noisy re-observations of
+shared "landmarks" (true matches at Hamming distance ~10-60), exact duplicates
+inside a set (lowest-index tie-breaking, keypoints.h:273), near-duplicates
+inside a set (ratio-test failures, keypoints.h:296) and fresh random
+descriptors (threshold failures).
+
+Everything is a pure function of (sizes, seed) built on a counter-based
+splitmix64, so the CPU oracle, the GPU path and every rank of a multi-GPU run
+regenerate identical bytes without shipping data.
+
+Descriptor layout: ``uint64[n, 4]``, bit k of the reference's
+``std::bitset<256>`` (keypoints.h:53) = bit ``k % 64`` of word ``k // 64``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * _M1
+    z = (z ^ (z >> np.uint64(27))) * _M2
+    return z ^ (z >> np.uint64(31))
+
+
+def _key(seed: int, stream: int) -> np.uint64:
+    with np.errstate(over="ignore"):
+        k = np.array([seed & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+        s = np.array([stream & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+        return _mix(_mix(k + _GOLDEN) ^ (s * _M2 + _GOLDEN))[0]
+
+
+def u64(seed: int, stream: int, shape) -> np.ndarray:
+    """Counter-based splitmix64: element i = mix(key(seed, stream) + (i+1)*golden)."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        ctr = np.arange(1, n + 1, dtype=np.uint64) * _GOLDEN + _key(seed, stream)
+        return _mix(ctr).reshape(shape)
+
+
+def random_descriptors(n: int, seed: int, stream: int = 0) -> np.ndarray:
+    """n iid Bernoulli(1/2) 256-bit descriptors."""
+    return u64(seed, 0x1000 + stream, (n, 4))
+
+
+def flip_masks(n: int, seed: int, stream: int, levels=(3, 4, 5)) -> np.ndarray:
+    """XOR masks with per-descriptor bit density 2**-m, m drawn from `levels`
+    (AND of m random words): m=3 -> ~32 flipped bits, 4 -> ~16, 5 -> ~8."""
+    lv = np.asarray(levels, dtype=np.int64)
+    pick = lv[(u64(seed, 0x2000 + stream, (n,)) % np.uint64(len(lv))).astype(np.int64)]
+    mask = np.full((n, 4), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    for k in range(int(lv.max())):
+        r = u64(seed, 0x3000 + 64 * stream + k, (n, 4))
+        use = (pick > k)[:, None]
+        mask = np.where(use, mask & r, mask)
+    return mask
+
+
+def _permutation(n: int, seed: int, stream: int) -> np.ndarray:
+    return np.argsort(u64(seed, 0x4000 + stream, (n,)), kind="stable")
+
+
+def _plant_intra(desc: np.ndarray, seed: int, stream: int, dup_frac: float,
+                 confuse_frac: float) -> None:
+    """In place: exact duplicates and near-duplicates inside one set."""
+    n = desc.shape[0]
+    if n < 4:
+        return
+    n_dup = int(n * dup_frac)
+    n_con = int(n * confuse_frac)
+    pos = _permutation(n, seed, 0x100 + stream)
+    src = pos[: n_dup + n_con]
+    dst = pos[n_dup + n_con: 2 * (n_dup + n_con)]
+    m = min(len(src), len(dst))
+    src, dst = src[:m], dst[:m]
+    noise = flip_masks(m, seed, 0x200 + stream, levels=(5, 6))  # ~8 / ~4 bits
+    noise[: min(n_dup, m)] = 0  # the first n_dup copies are exact duplicates
+    desc[dst] = desc[src] ^ noise
+
+
+def orb_like_pair(n1: int, n2: int, seed: int, match_frac: float = 0.7,
+                  dup_frac: float = 0.02, confuse_frac: float = 0.02):
+    """A stereo-like pair: set 2 holds noisy copies of
+    `match_frac` of set 1 (shuffled), the rest fresh; both sets carry
+    intra-set duplicates and near-duplicates."""
+    a = random_descriptors(n1, seed, 1)
+    _plant_intra(a, seed, 1, dup_frac, confuse_frac)
+    b = random_descriptors(n2, seed, 2)
+    n_m = int(min(n1, n2) * match_frac)
+    src = _permutation(n1, seed, 3)[:n_m]
+    dst = _permutation(n2, seed, 4)[:n_m]
+    b[dst] = a[src] ^ flip_masks(n_m, seed, 5)
+    _plant_intra(b, seed, 2, dup_frac, confuse_frac)
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def planted_sets(n: int, seed: int, planted_frac: float = 0.5):
+    """Config 4 (1M x 1M): set B = shuffled A with `planted_frac` noisy copies,
+    the rest fresh random."""
+    return orb_like_pair(n, n, seed, match_frac=planted_frac, dup_frac=0.001,
+                         confuse_frac=0.001)
+
+
+def sfm_database(n_img: int, n_desc, seed: int, share_frac: float = 0.4,
+                 window: int = 5, dup_frac: float = 0.01, confuse_frac: float = 0.01):
+    """A database of `n_img` images for all-pairs SfM matching (configs 3, 5).
+
+    Image i re-observes a sliding window of global landmarks so that images
+    whose ids differ by k < `window` share about share_frac*(1 - k/window) of
+    their descriptors (noisy copies); the rest are fresh.  `n_desc` is an int
+    (every image that size) or a sequence of per-image sizes (ragged database).
+
+    Returns (desc uint64[total, 4], offsets uint32[n_img + 1]).
+    """
+    sizes = np.full(n_img, n_desc, dtype=np.int64) if np.isscalar(n_desc) \
+        else np.asarray(n_desc, dtype=np.int64)
+    assert sizes.shape == (n_img,)
+    offsets = np.zeros(n_img + 1, dtype=np.uint32)
+    offsets[1:] = np.cumsum(sizes)
+    total = int(offsets[-1])
+    desc = random_descriptors(total, seed, 10)
+    n_max = int(sizes.max()) if n_img else 0
+    n_shared_max = int(n_max * share_frac)
+    stride = max(1, n_shared_max // max(1, window))
+    n_landmarks = stride * (n_img + window + 1) + n_shared_max
+    landmarks = random_descriptors(n_landmarks, seed, 11)
+    noise_all = flip_masks(total, seed, 12)
+    for i in range(n_img):
+        lo, hi = int(offsets[i]), int(offsets[i + 1])
+        n = hi - lo
+        n_sh = min(int(n * share_frac), n_shared_max)
+        if n_sh > 0:
+            slot = _permutation(n, seed, 0x10000 + i)[:n_sh]
+            lm = i * stride + np.arange(n_sh)
+            desc[lo + slot] = landmarks[lm] ^ noise_all[lo + slot]
+        view = desc[lo:hi]
+        _plant_intra(view, seed, 0x20000 + i, dup_frac, confuse_frac)
+    return np.ascontiguousarray(desc), offsets
+
+
+def all_pairs(n_img: int, frame_of=None) -> np.ndarray:
+    """Pair enumeration of src/sfm.cpp:1285-1290: (i, j) for j < i, skipping
+    pairs of the same frame (stereo pairs).  `frame_of[i]` is image i's frame
+    id; None = every image its own frame.  Returns uint32[n_pairs, 2]."""
+    i, j = np.tril_indices(n_img, k=-1)
+    if frame_of is not None:
+        f = np.asarray(frame_of)
+        keep = f[i] != f[j]
+        i, j = i[keep], j[keep]
+    return np.ascontiguousarray(np.stack([i, j], axis=1).astype(np.uint32))
