@@ -1,0 +1,137 @@
+/*
+ * vsmatch.h -- C ABI of libvsmatch.so, the MI355X (gfx950) drop-in for the
+ * brute-force ORB descriptor matcher of berkaygumus/visual-SLAM:
+ *
+ *     void visnav::matchDescriptors(
+ *         const std::vector<std::bitset<256>>& corner_descriptors_1,
+ *         const std::vector<std::bitset<256>>& corner_descriptors_2,
+ *         std::vector<std::pair<int, int>>& matches,
+ *         int threshold, double dist_2_best);      // include/visnav/keypoints.h:247-250
+ *
+ * Plain pointers and sizes only.  The C++ shim with the reference's exact
+ * signature is include/visnav_amd/keypoints_gpu.h; the reference-side bindings
+ * are shown in INTEGRATION.md.
+ *
+ * Descriptor layout everywhere: one descriptor = 4 little-endian uint64 words
+ * (32 bytes); bit k of the reference's std::bitset<256> (keypoints.h:53) is bit
+ * k % 64 of word k / 64 -- the in-memory image of the bitset on libstdc++ and
+ * libc++ x86-64, so `reinterpret_cast<const uint64_t*>(vec.data())` is a
+ * zero-copy view of `KeypointsData::corner_descriptors` (common_types.h:121).
+ *
+ * Match lists are int32 pairs (first, second) = (index into set 1, index into
+ * set 2), the layout of `std::vector<std::pair<int,int>>`
+ * (`MatchData::matches`, common_types.h:133), in the reference's order
+ * (ascending `first`, keypoints.h:354-360).
+ *
+ * Every function returns VSM_OK (0) or an error code; vsm_last_error() gives
+ * the message of the calling thread's last failure.  There is no CPU fallback:
+ * without a usable GPU every entry point fails with VSM_ERR_HIP.
+ *
+ * Threading: a vsm_ctx serialises its calls with an internal mutex; use one
+ * context per thread for concurrency (the C++ shim keeps a thread_local one,
+ * which makes it re-entrant for the tbb::parallel_for of src/sfm.cpp:1295).
+ */
+#ifndef VSMATCH_H
+#define VSMATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsm_ctx vsm_ctx;
+
+enum {
+  VSM_OK = 0,
+  VSM_ERR_INVALID = 1,  /* bad argument */
+  VSM_ERR_HIP = 2,      /* a HIP runtime call failed / no device */
+  VSM_ERR_CAPACITY = 3, /* caller's output buffer too small; *out_count / *out_total holds the need */
+  VSM_ERR_NOMEM = 4
+};
+
+/* Largest descriptor set (one side of a match, or one image of a database)
+ * the kernels index: 2^23 = 8,388,608 descriptors (23-bit index field of the
+ * packed (distance, index) key). */
+#define VSM_MAX_SET ((size_t)1 << 23)
+
+int vsm_version(void);
+const char* vsm_last_error(void);
+
+/* Context = one HIP device + one stream + device scratch owned by the library. */
+int vsm_create(int device, vsm_ctx** out);
+void vsm_destroy(vsm_ctx* ctx);
+/* The HIP stream (hipStream_t) all work of this context is enqueued on. */
+void* vsm_stream(vsm_ctx* ctx);
+
+/*
+ * Replaces visnav::matchDescriptors, keypoints.h:247-361 (called at
+ * src/sfm.cpp:1243, src/odometry.cpp:814, src/point_cloud_localization.cpp:873,
+ * test/src/test_ex3.cpp:164).  d1/d2: host pointers to n1/n2 packed
+ * descriptors, borrowed for the call.  out_pairs: host buffer for cap_pairs
+ * (first, second) pairs; min(n1, n2) always suffices.  *out_count = number of
+ * matches.  VSM_ERR_CAPACITY if it exceeds cap_pairs (nothing is written then).
+ */
+int vsm_match_pair(vsm_ctx* ctx, const uint64_t* d1, size_t n1, const uint64_t* d2,
+                   size_t n2, int threshold, double dist_2_best, int32_t* out_pairs,
+                   size_t cap_pairs, size_t* out_count);
+
+/*
+ * One direction of the scan, keypoints.h:256-290 (== 305-339 with the roles
+ * swapped), before the accept test: for each query the lowest-index nearest
+ * train descriptor, its distance and the second smallest distance.  best_idx
+ * is -1 and both distances 256 where nothing closer than 256 exists
+ * (keypoints.h:259-262).  Host pointers; int32[nq] outputs.  (Config "1M x 1M,
+ * 1-NN + ratio test" of BASELINE.json.)
+ */
+int vsm_nn2(vsm_ctx* ctx, const uint64_t* query, size_t nq, const uint64_t* train,
+            size_t nt, int32_t* best_idx, int32_t* best_dist, int32_t* second_dist);
+/* Same with every pointer a DEVICE pointer (inputs already in HBM, outputs stay
+ * there); returns after enqueueing, the caller synchronises vsm_stream(). */
+int vsm_nn2_device(vsm_ctx* ctx, const void* d_query, size_t nq, const void* d_train,
+                   size_t nt, void* d_best_idx, void* d_best_dist, void* d_second_dist);
+
+/*
+ * Descriptor database = the `feature_corners` map of src/sfm.cpp:1191-1214
+ * flattened: image i owns descriptors offsets[i] .. offsets[i+1]-1 of `desc`.
+ * upload copies host memory into HBM; attach borrows a DEVICE pointer (e.g. a
+ * buffer an RCCL broadcast has just filled) that must outlive its use.
+ * offsets is a host array of n_img + 1 entries either way.
+ */
+int vsm_db_upload(vsm_ctx* ctx, const uint64_t* desc, const uint32_t* offsets, size_t n_img);
+int vsm_db_attach(vsm_ctx* ctx, const void* d_desc, const uint32_t* offsets, size_t n_img);
+
+/*
+ * The match_all / match_bow call pattern, src/sfm.cpp:1295-1321 and 1397-1423:
+ * matchDescriptors(db[pairs[k][0]], db[pairs[k][1]], ...) for every k, as one
+ * batch.  pairs: host uint32[n_pairs][2] image indices.  out_offsets: host
+ * uint64[n_pairs + 1]; pair k's matches are out_pairs[out_offsets[k] ..
+ * out_offsets[k+1]) (each list in the reference's order).  *out_total =
+ * out_offsets[n_pairs].  VSM_ERR_CAPACITY if that exceeds cap_pairs
+ * (out_offsets is valid then, out_pairs holds the first cap_pairs).
+ */
+int vsm_match_pairs(vsm_ctx* ctx, const uint32_t* pairs, size_t n_pairs, int threshold,
+                    double dist_2_best, uint64_t* out_offsets, int32_t* out_pairs,
+                    size_t cap_pairs, size_t* out_total);
+/* Same with d_pairs, d_out_offsets, d_out_pairs DEVICE pointers; blocks until
+ * the batch is done (it has to read the total back). */
+int vsm_match_pairs_device(vsm_ctx* ctx, const void* d_pairs, size_t n_pairs, int threshold,
+                           double dist_2_best, void* d_out_offsets, void* d_out_pairs,
+                           size_t cap_pairs, size_t* out_total);
+
+/*
+ * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of
+ * the last batched/nn2 call, measured with HIP events on the context's stream,
+ * how many launches that was and how many 256-bit comparisons they evaluated.
+ */
+int vsm_last_scan_stats(vsm_ctx* ctx, double* ms, uint64_t* launches, uint64_t* comparisons);
+/* Enable/disable the event timing above (off by default; costs two events per launch). */
+int vsm_set_profiling(vsm_ctx* ctx, int enabled);
+/* Kernel variant selector for experiments: 0 = default. See DESIGN.md. */
+int vsm_set_variant(vsm_ctx* ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSMATCH_H */
