@@ -1,0 +1,132 @@
+"""GPU parity: the HIP path through the C ABI against the oracle, the recorded
+outputs of the real reference function and the reference's own golden vector.
+Bar: bit-exact (integer/index work)."""
+import hashlib
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+vsm = importlib.import_module("visual-slam_amd")
+
+with open(os.path.join(cases.GOLDEN, "ref_cases.json")) as f:
+    REF = json.load(f)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.int32).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def m():
+    with vsm.Matcher(0) as mm:
+        yield mm
+
+
+def test_ex3_golden_vector(m):
+    """test_ex3.cpp:148-185 on the GPU, order included."""
+    d1, d2 = cases.ex3()
+    want = np.load(os.path.join(cases.GOLDEN, "ex3_matches.npy"))
+    assert np.array_equal(m.match(d1, d2, 70, 1.2), want)
+    assert np.array_equal(vsm.match_descriptors(d1, d2, 70, 1.2), want)
+
+
+@pytest.mark.parametrize("name", cases.case_names())
+def test_pair_matches_recorded_reference(m, name):
+    d1, d2, thr, ratio = cases.build_case(name)
+    rec = REF["cases"][name]
+    got = m.match(d1, d2, thr, ratio)
+    assert len(got) == rec["count"]
+    assert sha(got) == rec["sha256"]
+    assert np.array_equal(got, binding.port().match(d1, d2, thr, ratio))
+
+
+@pytest.mark.parametrize("variant", [1, 4, 8])
+def test_pair_all_kernel_shapes(m, variant):
+    """Every queries-per-lane instantiation gives the same list."""
+    m.set_variant(variant)
+    try:
+        for name in ("ex3_thr70_r1.2", "planted_300x777", "planted_1023x1025", "planted_4100x130",
+                     "edge_all_identical", "edge_all_256_thr300_ratio1", "edge_tie_best"):
+            d1, d2, thr, ratio = cases.build_case(name)
+            assert sha(m.match(d1, d2, thr, ratio)) == REF["cases"][name]["sha256"], (variant, name)
+    finally:
+        m.set_variant(0)
+
+
+def test_nn2_vs_oracle(m):
+    for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6)]:
+        q, t = cases.synth.orb_like_pair(nq, nt, seed)
+        got = m.nn2(q, t)
+        want = binding.port().nn2(q, t)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), (nq, nt)
+    q, _ = cases.synth.orb_like_pair(10, 10, 9)
+    bi, bd, sd = m.nn2(q, np.zeros((0, 4), np.uint64))
+    assert list(bi) == [-1] * 10 and list(bd) == [256] * 10 and list(sd) == [256] * 10
+    bi, bd, sd = m.nn2(q[:1], q[:1] ^ cases.ONES)
+    assert (bi[0], bd[0], sd[0]) == (-1, 256, 256)
+
+
+def test_batched_small_ragged_database(m):
+    """match_all pattern (sfm.cpp:1276-1321) on a ragged database incl. empty images."""
+    db, off, pairs = cases.sfm_small()
+    m.db_upload(db, off)
+    offs, out = m.match_pairs(pairs, 70, 1.2)
+    recs = REF["sfm_small"]["pairs"]
+    assert int(offs[0]) == 0 and int(offs[-1]) == len(out)
+    for k, r in enumerate(recs):
+        got = out[int(offs[k]):int(offs[k + 1])]
+        assert len(got) == r["count"] and sha(got) == r["sha256"], (k, r["pair"])
+    # both orientations and repeated pairs
+    pp = np.concatenate([pairs[:, ::-1], pairs[:3]])
+    offs, out = m.match_pairs(pp, 70, 1.2)
+    for k, (i, j) in enumerate(pp.tolist()):
+        want = binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], want)
+    offs, out = m.match_pairs(np.zeros((0, 2), np.uint32))
+    assert list(offs) == [0] and len(out) == 0
+
+
+def test_batched_uniform_database_vs_oracle(m):
+    db, off = cases.synth.sfm_database(24, 700, seed=33)
+    pairs = cases.synth.all_pairs(24)
+    m.db_upload(db, off)
+    offs, out = m.match_pairs(pairs, 70, 1.2)
+    total = 0
+    for k, (i, j) in enumerate(pairs.tolist()):
+        want = binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], want), (i, j)
+        total += len(want)
+    assert total == len(out) and total > 1000  # the planted overlap is really there
+
+
+def test_capacity_and_errors(m):
+    d1, d2, thr, ratio = cases.build_case("planted_300x777")
+    L = vsm.matcher.lib()
+    import ctypes as C
+    out = np.empty((4, 2), np.int32)
+    n = C.c_size_t(0)
+    rc = L.vsm_match_pair(m._h, d1.ctypes.data, len(d1), d2.ctypes.data, len(d2), thr, ratio,
+                          out.ctypes.data, 4, C.byref(n))
+    assert rc == vsm.matcher.VSM_ERR_CAPACITY and n.value == REF["cases"]["planted_300x777"]["count"]
+    db, off, pairs = cases.sfm_small()
+    m.db_upload(db, off)
+    with pytest.raises(vsm.VsmError):
+        m.match_pairs(np.array([[0, 99]], np.uint32), cap=10)
+
+
+def test_property_swap_transposes(m):
+    """Swapping the arguments gives the transposed set at full size."""
+    a, b = cases.synth.orb_like_pair(2000, 1900, seed=77)
+    ab = m.match(a, b, 70, 1.2)
+    ba = m.match(b, a, 70, 1.2)
+    assert len(ab) > 500
+    assert sorted(map(tuple, ab.tolist())) == sorted((y, x) for x, y in ba.tolist())
+    assert np.all(np.diff(ab[:, 0]) > 0) and np.all(np.diff(ba[:, 0]) > 0)

@@ -1,0 +1,586 @@
+// vsmatch.hip -- C ABI (include/vsmatch.h) over the gfx950 kernels.
+//
+// Replaces visnav::matchDescriptors (/root/reference/include/visnav/keypoints.h:247-361)
+// and its batched call pattern (src/sfm.cpp:1295-1321).  No CPU fallback: every
+// entry point needs a HIP device and fails with VSM_ERR_HIP otherwise.
+#include "vsmatch_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "vsmatch.h"
+
+using namespace vsm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(VSM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+#define VSM_TRY(expr)         \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != VSM_OK) return rc_; \
+  } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return VSM_OK;
+    if (p) {
+      HIP_TRY(hipFree(p));
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = std::max(bytes + bytes / 4, (size_t)4096);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(VSM_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    cap = want;
+    return VSM_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return VSM_OK;
+    if (p) {
+      HIP_TRY(hipHostFree(p));
+      p = nullptr;
+      cap = 0;
+    }
+    size_t want = std::max(bytes + bytes / 4, (size_t)4096);
+    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return VSM_OK;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+constexpr size_t DESC_BYTES = 32;
+constexpr size_t SCRATCH_BUDGET = (size_t)2 << 30;  // scan results per chunk of pairs
+constexpr u32 TARGET_WAVES = 4096;                  // below this the train range is split
+
+}  // namespace
+
+struct vsm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::recursive_mutex mu;
+  // database
+  const void* db = nullptr;
+  DevBuf db_owned;
+  DevBuf d_img_off;
+  std::vector<u32> img_off;
+  u32 max_n = 0;
+  // work buffers
+  DevBuf stage, scratch, jobs, counts, misc, w_pairs, w_offsets, w_out;
+  PinBuf pin;
+  // measurement
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  double scan_ms = 0;
+  u64 scan_launches = 0, scan_comps = 0;
+  int variant = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+void make_accept(int threshold, double dist_2_best, AcceptParams* prm) {
+  prm->threshold = threshold;
+  for (int b = 0; b <= 256; b++) {
+    int need = 257;
+    for (int s = 0; s <= 256; s++) {
+      // keypoints.h:296, evaluated in double exactly as the reference does
+      if (dist_2_best * b <= s) {
+        need = s;
+        break;
+      }
+    }
+    prm->min_second[b] = (uint16_t)need;
+  }
+  prm->min_second[257] = 257;
+}
+
+int ev_pair(vsm_ctx* c, hipEvent_t* a, hipEvent_t* b) {
+  while (c->ev.size() < c->ev_used + 2) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    c->ev.push_back(e);
+  }
+  *a = c->ev[c->ev_used++];
+  *b = c->ev[c->ev_used++];
+  return VSM_OK;
+}
+
+void stats_reset(vsm_ctx* c) {
+  c->ev_used = 0;
+  c->scan_ms = 0;
+  c->scan_launches = 0;
+  c->scan_comps = 0;
+}
+
+// After the stream has been synchronised: sum the event pairs.
+int stats_collect(vsm_ctx* c) {
+  for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+    c->scan_ms += ms;
+  }
+  c->ev_used = 0;
+  return VSM_OK;
+}
+
+struct ScanShape {
+  int R;
+  u32 wgs_per_job, splits;
+};
+
+// Queries per wave (64*R) and train splits.  Large batches: R = 4, no split.
+// Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
+// query per lane and the train range split over grid.y so that all 256 CUs work.
+ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
+  ScanShape s;
+  const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256);
+  s.R = waves_r4 >= TARGET_WAVES ? 4 : 1;
+  if (variant == 1) s.R = 1;
+  if (variant == 4) s.R = 4;
+  if (variant == 8) s.R = 8;
+  const u32 tq = 64 * s.R;
+  const u32 tiles = (max_nq + tq - 1) / tq;
+  s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
+  const u64 waves = std::max<u64>(1, n_jobs * tiles);
+  u32 splits = 1;
+  if (waves < TARGET_WAVES) splits = (u32)((TARGET_WAVES + waves - 1) / waves);
+  splits = std::min(splits, std::max(1u, max_nt / 32));  // at least 32 train items per split
+  s.splits = std::min(std::max(splits, 1u), 256u);
+  return s;
+}
+
+int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
+                const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps) {
+  if (n_jobs == 0) return VSM_OK;
+  const u64 blocks = n_jobs * sh.wgs_per_job;
+  if (blocks > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks);
+  dim3 grid((u32)blocks, sh.splits), block(256);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->profiling) {
+    VSM_TRY(ev_pair(c, &e0, &e1));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+  }
+  const u32x4* q = (const u32x4*)qbase;
+  const u32x4* t = (const u32x4*)tbase;
+  switch (sh.R) {
+    case 1: hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    case 4: hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    case 8: hipLaunchKernelGGL(scan_kernel<8>, grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
+  }
+  HIP_TRY(hipGetLastError());
+  if (c->profiling) HIP_TRY(hipEventRecord(e1, c->stream));
+  c->scan_launches++;
+  c->scan_comps += comps;
+  return VSM_OK;
+}
+
+u32 round_up(u32 v, u32 m) { return (v + m - 1) / m * m; }
+
+// The batched matcher on device-resident inputs.  d_desc/d_img_off describe
+// the database the pairs index; results go to caller-provided device memory.
+int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32 n_img, u32 max_n,
+                       const uint2* d_pairs, size_t n_pairs,
+                       const AcceptParams& prm, u64* d_out_offsets, int2* d_out_pairs,
+                       size_t cap_pairs, size_t* out_total) {
+  // `misc`: [u64 running total][u64 comparisons evaluated][u32 bad-pair flag]
+  VSM_TRY(c->misc.reserve(64));
+  u64* d_running = (u64*)c->misc.p;
+  u64* d_comps = d_running + 1;
+  u32* d_bad = (u32*)(d_running + 2);
+  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 32, c->stream));
+  if (n_pairs == 0) {
+    HIP_TRY(hipMemsetAsync(d_out_offsets, 0, sizeof(u64), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out_total = 0;
+    return VSM_OK;
+  }
+  const u32 stride = std::max(64u, round_up(max_n, 64));
+  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant);
+  // chunk so that scratch (8 B per query per split, both directions) fits the budget
+  const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
+  u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
+  chunk = std::min<u64>(chunk, n_pairs);
+  chunk = std::min<u64>(chunk, 0xffffffffull / ((u64)2 * stride) / 2);
+  const u64 split_stride = chunk * 2 * stride;
+  if (split_stride * sh.splits > 0xffffffffull) return fail(VSM_ERR_INVALID, "scratch index overflow");
+  VSM_TRY(c->scratch.reserve(split_stride * sh.splits * sizeof(uint2)));
+  VSM_TRY(c->jobs.reserve(chunk * 2 * sizeof(Job)));
+  VSM_TRY(c->counts.reserve(chunk * sizeof(u32)));
+  Job* d_jobs = (Job*)c->jobs.p;
+  uint2* d_scratch = (uint2*)c->scratch.p;
+  u32* d_counts = (u32*)c->counts.p;
+
+  for (u64 first = 0; first < n_pairs; first += chunk) {
+    const u32 n = (u32)std::min<u64>(chunk, n_pairs - first);
+    hipLaunchKernelGGL(plan_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                       d_pairs + first, n, d_img_off, n_img, stride, d_jobs, d_bad, d_comps);
+    HIP_TRY(hipGetLastError());
+    VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0));
+    hipLaunchKernelGGL(count_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
+                       sh.splits, (u32)split_stride, prm, d_counts);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, d_counts, n,
+                       d_out_offsets, first, d_running);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, sh.splits,
+                       (u32)split_stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);
+    HIP_TRY(hipGetLastError());
+  }
+  struct {
+    u64 total, comps;
+    u32 bad;
+    u32 pad;
+  } h;
+  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 24, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->profiling) VSM_TRY(stats_collect(c));
+  c->scan_comps = h.comps;
+  *out_total = (size_t)h.total;
+  if (h.bad) return fail(VSM_ERR_INVALID, "a pair names an image index >= %u", n_img);
+  if (h.total > cap_pairs)
+    return fail(VSM_ERR_CAPACITY, "%llu matches need more than cap_pairs=%zu", (unsigned long long)h.total, cap_pairs);
+  return VSM_OK;
+}
+
+int check_ctx(vsm_ctx* c) {
+  if (!c) return fail(VSM_ERR_INVALID, "null context");
+  return VSM_OK;
+}
+
+int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
+  if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
+  if (n_img >= 0xffffffffull) return fail(VSM_ERR_INVALID, "too many images");
+  u32 max_n = 0;
+  for (size_t i = 0; i < n_img; i++) {
+    if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
+    max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
+  }
+  if (max_n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "image with %u descriptors exceeds VSM_MAX_SET", max_n);
+  if (n_img && !d_desc && offsets[n_img] != 0) return fail(VSM_ERR_INVALID, "null descriptor pointer");
+  VSM_TRY(c->d_img_off.reserve((n_img + 1) * sizeof(u32)));
+  HIP_TRY(hipMemcpyAsync(c->d_img_off.p, offsets, (n_img + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->img_off.assign(offsets, offsets + n_img + 1);
+  c->max_n = max_n;
+  c->db = d_desc;
+  return VSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsm_version(void) { return 100; }
+
+const char* vsm_last_error(void) { return g_err; }
+
+int vsm_create(int device, vsm_ctx** out) {
+  if (!out) return fail(VSM_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(VSM_ERR_HIP, "no HIP device available (%s); libvsmatch has no CPU fallback",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(VSM_ERR_INVALID, "device %d out of range [0, %d)", device, n);
+  DeviceGuard g(device);
+  if (!g.ok) return fail(VSM_ERR_HIP, "hipSetDevice(%d) failed", device);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(VSM_ERR_HIP, "device %d is %s; libvsmatch is built for gfx950 only", device, prop.gcnArchName);
+  vsm_ctx* c = new (std::nothrow) vsm_ctx;
+  if (!c) return fail(VSM_ERR_NOMEM, "out of host memory");
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(VSM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return VSM_OK;
+}
+
+void vsm_destroy(vsm_ctx* c) {
+  if (!c) return;
+  {
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc,
+                      &c->w_pairs, &c->w_offsets, &c->w_out})
+      b->release();
+    c->pin.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+void* vsm_stream(vsm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vsm_set_profiling(vsm_ctx* c, int enabled) {
+  VSM_TRY(check_ctx(c));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->profiling = enabled != 0;
+  return VSM_OK;
+}
+
+int vsm_set_variant(vsm_ctx* c, int variant) {
+  VSM_TRY(check_ctx(c));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->variant = variant;
+  return VSM_OK;
+}
+
+int vsm_last_scan_stats(vsm_ctx* c, double* ms, uint64_t* launches, uint64_t* comparisons) {
+  VSM_TRY(check_ctx(c));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (ms) *ms = c->scan_ms;
+  if (launches) *launches = c->scan_launches;
+  if (comparisons) *comparisons = c->scan_comps;
+  return VSM_OK;
+}
+
+int vsm_db_upload(vsm_ctx* c, const uint64_t* desc, const uint32_t* offsets, size_t n_img) {
+  VSM_TRY(check_ctx(c));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
+  const size_t total = offsets[n_img];
+  if (total && !desc) return fail(VSM_ERR_INVALID, "null descriptor pointer");
+  VSM_TRY(c->db_owned.reserve(std::max<size_t>(total * DESC_BYTES, 256)));
+  if (total) HIP_TRY(hipMemcpyAsync(c->db_owned.p, desc, total * DESC_BYTES, hipMemcpyHostToDevice, c->stream));
+  return set_db(c, c->db_owned.p, offsets, n_img);
+}
+
+int vsm_db_attach(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
+  VSM_TRY(check_ctx(c));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  return set_db(c, d_desc, offsets, n_img);
+}
+
+int vsm_match_pairs_device(vsm_ctx* c, const void* d_pairs, size_t n_pairs, int threshold,
+                           double dist_2_best, void* d_out_offsets, void* d_out_pairs,
+                           size_t cap_pairs, size_t* out_total) {
+  VSM_TRY(check_ctx(c));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (!out_total || !d_out_offsets) return fail(VSM_ERR_INVALID, "null output pointer");
+  if (n_pairs && !d_pairs) return fail(VSM_ERR_INVALID, "null pairs pointer");
+  if (cap_pairs && !d_out_pairs) return fail(VSM_ERR_INVALID, "null out_pairs with non-zero capacity");
+  if (c->img_off.empty()) return fail(VSM_ERR_INVALID, "no database: call vsm_db_upload/vsm_db_attach first");
+  AcceptParams prm;
+  make_accept(threshold, dist_2_best, &prm);
+  stats_reset(c);
+  return match_pairs_device(c, c->db, (const u32*)c->d_img_off.p, (u32)(c->img_off.size() - 1), c->max_n,
+                            (const uint2*)d_pairs, n_pairs, prm, (u64*)d_out_offsets,
+                            (int2*)d_out_pairs, cap_pairs, out_total);
+}
+
+int vsm_match_pairs(vsm_ctx* c, const uint32_t* pairs, size_t n_pairs, int threshold,
+                    double dist_2_best, uint64_t* out_offsets, int32_t* out_pairs, size_t cap_pairs,
+                    size_t* out_total) {
+  VSM_TRY(check_ctx(c));
+  if (!out_total || !out_offsets) return fail(VSM_ERR_INVALID, "null output pointer");
+  if (n_pairs && !pairs) return fail(VSM_ERR_INVALID, "null pairs pointer");
+  if (cap_pairs && !out_pairs) return fail(VSM_ERR_INVALID, "null out_pairs with non-zero capacity");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  VSM_TRY(c->w_pairs.reserve(std::max<size_t>(n_pairs * 8, 8)));
+  VSM_TRY(c->w_offsets.reserve((n_pairs + 1) * 8));
+  VSM_TRY(c->w_out.reserve(std::max<size_t>(cap_pairs * 8, 8)));
+  if (n_pairs) HIP_TRY(hipMemcpyAsync(c->w_pairs.p, pairs, n_pairs * 8, hipMemcpyHostToDevice, c->stream));
+  int rc = vsm_match_pairs_device(c, c->w_pairs.p, n_pairs, threshold, dist_2_best, c->w_offsets.p,
+                                  c->w_out.p, cap_pairs, out_total);
+  if (rc != VSM_OK && rc != VSM_ERR_CAPACITY) return rc;
+  HIP_TRY(hipMemcpyAsync(out_offsets, c->w_offsets.p, (n_pairs + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  const size_t n_copy = std::min(*out_total, cap_pairs);
+  if (n_copy) HIP_TRY(hipMemcpyAsync(out_pairs, c->w_out.p, n_copy * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return rc;
+}
+
+int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2, size_t n2,
+                   int threshold, double dist_2_best, int32_t* out_pairs, size_t cap_pairs,
+                   size_t* out_count) {
+  VSM_TRY(check_ctx(c));
+  if (!out_count) return fail(VSM_ERR_INVALID, "null out_count");
+  if ((n1 && !d1) || (n2 && !d2)) return fail(VSM_ERR_INVALID, "null descriptor pointer");
+  if (n1 > VSM_MAX_SET || n2 > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "set larger than VSM_MAX_SET");
+  if (cap_pairs && !out_pairs) return fail(VSM_ERR_INVALID, "null out_pairs with non-zero capacity");
+  *out_count = 0;
+  if (n1 == 0 || n2 == 0) return VSM_OK;  // keypoints.h:251: matches.clear(), nothing to add
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  stats_reset(c);
+  AcceptParams prm;
+  make_accept(threshold, dist_2_best, &prm);
+
+  // One pinned staging block: [d1 | d2 | Job f | Job b] up, [offsets(2 x u64) | pairs] down.
+  const size_t nmin = std::min(n1, n2);
+  const size_t up_bytes = (n1 + n2) * DESC_BYTES + 2 * sizeof(Job);
+  const size_t down_bytes = 16 + nmin * 8;
+  VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
+  VSM_TRY(c->stage.reserve(up_bytes));
+  VSM_TRY(c->w_out.reserve(down_bytes));
+  char* h = (char*)c->pin.p;
+  memcpy(h, d1, n1 * DESC_BYTES);
+  memcpy(h + n1 * DESC_BYTES, d2, n2 * DESC_BYTES);
+  const u32 stride = std::max(64u, round_up((u32)std::max(n1, n2), 64));
+  Job jf = {0, (u32)n1, (u32)n1, (u32)n2, 0, 0, 0, 0};
+  Job jb = {(u32)n1, (u32)n2, 0, (u32)n1, stride, 0, 0, 0};
+  memcpy(h + (n1 + n2) * DESC_BYTES, &jf, sizeof jf);
+  memcpy(h + (n1 + n2) * DESC_BYTES + sizeof jf, &jb, sizeof jb);
+  HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+  const Job* d_jobs = (const Job*)((char*)c->stage.p + (n1 + n2) * DESC_BYTES);
+
+  const ScanShape sh = choose_shape(2, (u32)std::max(n1, n2), (u32)std::max(n1, n2), c->variant);
+  const u32 split_stride = 2 * stride;
+  VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
+  VSM_TRY(c->counts.reserve(64));
+  VSM_TRY(c->misc.reserve(64));
+  u64* d_running = (u64*)c->misc.p;
+  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 16, c->stream));
+  VSM_TRY(launch_scan(c, c->stage.p, c->stage.p, d_jobs, 2, sh, split_stride, (uint2*)c->scratch.p,
+                      2ull * n1 * n2));
+  u64* d_off = (u64*)c->w_out.p;
+  int2* d_out = (int2*)((char*)c->w_out.p + 16);
+  hipLaunchKernelGGL(count_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
+                     sh.splits, split_stride, prm, (u32*)c->counts.p);
+  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->counts.p, 1u,
+                     d_off, (u64)0, d_running);
+  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
+                     sh.splits, split_stride, prm, (const u64*)d_off, (u64)0, d_out, (u64)nmin);
+  HIP_TRY(hipGetLastError());
+  char* hd = h + up_bytes;
+  HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->profiling) VSM_TRY(stats_collect(c));
+  u64 offs[2];
+  memcpy(offs, hd, 16);
+  const size_t count = (size_t)offs[1];
+  *out_count = count;
+  if (count > cap_pairs) return fail(VSM_ERR_CAPACITY, "%zu matches need more than cap_pairs=%zu", count, cap_pairs);
+  if (count) memcpy(out_pairs, hd + 16, count * 8);
+  return VSM_OK;
+}
+
+int vsm_nn2_device(vsm_ctx* c, const void* d_query, size_t nq, const void* d_train, size_t nt,
+                   void* d_best_idx, void* d_best_dist, void* d_second_dist) {
+  VSM_TRY(check_ctx(c));
+  if (nq == 0) return VSM_OK;
+  if (!d_query || (nt && !d_train) || !d_best_idx || !d_best_dist || !d_second_dist)
+    return fail(VSM_ERR_INVALID, "null pointer");
+  if (nt > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "train set of %zu exceeds VSM_MAX_SET", nt);
+  if (nq > 0xffffff00ull) return fail(VSM_ERR_INVALID, "query set too large");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  stats_reset(c);
+  const ScanShape sh = choose_shape(1, (u32)nq, (u32)nt, c->variant);
+  const u32 split_stride = round_up((u32)nq, 64);
+  if ((u64)split_stride * sh.splits > 0xffffffffull) return fail(VSM_ERR_INVALID, "scratch index overflow");
+  VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
+  VSM_TRY(c->jobs.reserve(sizeof(Job)));
+  VSM_TRY(c->pin.reserve(sizeof(Job)));
+  Job j = {0, (u32)nq, 0, (u32)nt, 0, 0, 0, 0};
+  memcpy(c->pin.p, &j, sizeof j);
+  HIP_TRY(hipMemcpyAsync(c->jobs.p, c->pin.p, sizeof j, hipMemcpyHostToDevice, c->stream));
+  VSM_TRY(launch_scan(c, d_query, nt ? d_train : d_query, (const Job*)c->jobs.p, 1, sh, split_stride,
+                      (uint2*)c->scratch.p, (u64)nq * nt));
+  hipLaunchKernelGGL(finalize_nn2_kernel, dim3((u32)((nq + 255) / 256)), dim3(256), 0, c->stream,
+                     (const uint2*)c->scratch.p, (u32)nq, sh.splits, split_stride, (int*)d_best_idx,
+                     (int*)d_best_dist, (int*)d_second_dist);
+  HIP_TRY(hipGetLastError());
+  if (c->profiling) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    VSM_TRY(stats_collect(c));
+  }
+  return VSM_OK;
+}
+
+int vsm_nn2(vsm_ctx* c, const uint64_t* query, size_t nq, const uint64_t* train, size_t nt,
+            int32_t* best_idx, int32_t* best_dist, int32_t* second_dist) {
+  VSM_TRY(check_ctx(c));
+  if (nq == 0) return VSM_OK;
+  if (!query || (nt && !train) || !best_idx || !best_dist || !second_dist)
+    return fail(VSM_ERR_INVALID, "null pointer");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  VSM_TRY(c->stage.reserve((nq + nt) * DESC_BYTES + 256));
+  VSM_TRY(c->w_out.reserve(nq * 12));
+  char* dq = (char*)c->stage.p;
+  char* dt = dq + nq * DESC_BYTES;
+  char* dout = (char*)c->w_out.p;
+  HIP_TRY(hipMemcpyAsync(dq, query, nq * DESC_BYTES, hipMemcpyHostToDevice, c->stream));
+  if (nt) HIP_TRY(hipMemcpyAsync(dt, train, nt * DESC_BYTES, hipMemcpyHostToDevice, c->stream));
+  VSM_TRY(vsm_nn2_device(c, dq, nq, dt, nt, dout, dout + nq * 4, dout + nq * 8));
+  HIP_TRY(hipMemcpyAsync(best_idx, dout, nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(best_dist, dout + nq * 4, nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(second_dist, dout + nq * 8, nq * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return VSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// vsmatch_kernels.h -- gfx950 (MI355X, wave64) kernels of the descriptor matcher.
+//
+// Path: visnav::matchDescriptors, /root/reference/include/visnav/keypoints.h:247-361.
+//
+//   scan_kernel      one direction of the brute-force scan (keypoints.h:256-290 and
+//                    305-339): per query the packed (distance, lowest index) of the
+//                    nearest train descriptor and the second smallest distance.
+//   count_kernel /   accept test (keypoints.h:295-296, 344-345) on both directions,
+//   fill_kernel      cross-check (354-360) and ordered compaction of the match list.
+//   finalize_nn2     unpacks the scan result for the raw 2-NN entry point.
+//
+// Integer VALU work only (v_xor_b32 + v_bcnt_u32_b32 with its free accumulate);
+// no MFMA by design: this is a popcount workload, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsm {
+
+using u32 = uint32_t;
+using u64 = uint64_t;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+
+// Packed key = (distance << 23) | train index.  Distances are 0..256 (9 bits),
+// so the key is a u32 whose unsigned order is (distance, index) lexicographic:
+// v_min_u32 on keys = "smaller distance, ties to the lower index", which is what
+// the reference's strict '<' in an ascending scan gives (keypoints.h:273).
+constexpr u32 IDX_BITS = 23;
+constexpr u32 IDX_MASK = (1u << IDX_BITS) - 1u;
+// Start value of best and second: distance 256, index 0.  A real key with
+// distance 256 is >= this, so "256 is never recorded" (keypoints.h:261-262, 273).
+constexpr u32 KEY_INIT = 256u << IDX_BITS;
+
+// One scan job: queries [q_off, q_off+nq) of qbase against train [t_off, t_off+nt)
+// of tbase; results go to scratch[out_off + query].  32 bytes so that a wave
+// fetches it with one s_load_dwordx8.
+struct __attribute__((aligned(32))) Job {
+  u32 q_off, nq, t_off, nt, out_off, pad0, pad1, pad2;
+};
+
+// Host-evaluated accept test.  min_second[b] = smallest s in [0, 256] with
+// dist_2_best * b <= s evaluated in double exactly as keypoints.h:296 does
+// (257 = no such s); the test is monotone in s, so `second >= min_second[best]`
+// is the same predicate with no floating point on the device.
+struct AcceptParams {
+  int threshold;
+  uint16_t min_second[258];
+};
+
+__device__ __forceinline__ u32 med3_u32(u32 a, u32 b, u32 c) {
+  u32 r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// popcount(x) + acc in one instruction (the accumulate operand of v_bcnt is free).
+// Written as asm because the compiler otherwise re-associates the eight counts
+// into v_bcnt(x, 0) + v_add3_u32 trees, three instructions more per comparison.
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
+  u32 r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ u32 bcnt0(u32 x) {
+  u32 r;
+  asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// One train descriptor (wave-uniform, in SGPRs) against the R query descriptors
+// each lane holds in VGPRs: 8 xor + 8 bcnt + key + med3 + min per comparison.
+// Invariant best <= second, so the new second is the median of (best, key, second).
+template <int R>
+__device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 j, u32 (&best)[R],
+                                       u32 (&second)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    u32 d = bcnt0(q[r][0] ^ t[0]);
+#pragma unroll
+    for (int w = 1; w < 8; w++) d = bcnt_acc(q[r][w] ^ t[w], d);
+    const u32 key = (d << IDX_BITS) | j;
+    second[r] = med3_u32(best[r], key, second[r]);
+    best[r] = min(best[r], key);
+  }
+}
+
+// Train descriptors are read through the constant address space so that the
+// wave-uniform loads become s_load_dwordx8 (scalar data cache, read only).
+typedef const __attribute__((address_space(4))) u32x8 cdesc_t;
+
+// Grid: x = job * wgs_per_job + workgroup-of-job, y = train split.  A wave is
+// the unit of work: it owns 64*R consecutive queries of one job (lane l holds
+// queries q0 + r*64 + l, so every query load is a coalesced 2 KiB) and scans
+// its split of the train range.  Waves never communicate; there is no LDS and
+// no barrier in this kernel.
+template <int R>
+__global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qbase,
+                                                   const u32x4* __restrict__ tbase,
+                                                   const Job* __restrict__ jobs, u32 wgs_per_job,
+                                                   u32 splits, u32 split_stride,
+                                                   uint2* __restrict__ scratch) {
+  constexpr u32 TQ = 64 * R;
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 job_id = blockIdx.x / wgs_per_job;
+  const u32 tile = (blockIdx.x - job_id * wgs_per_job) * 4 + wave;
+  const u32 split = blockIdx.y;
+  const Job job = jobs[job_id];
+  const u32 q0 = tile * TQ;
+  if (q0 >= job.nq) return;
+  const u32 per = (job.nt + splits - 1) / splits;
+  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
+
+  u32 q[R][8];
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const u32 qi = min(q0 + r * 64 + lane, job.nq - 1);
+    const u32x4* p = qbase + 2 * (size_t)(job.q_off + qi);
+    const u32x4 a = p[0], b = p[1];
+    q[r][0] = a.x; q[r][1] = a.y; q[r][2] = a.z; q[r][3] = a.w;
+    q[r][4] = b.x; q[r][5] = b.y; q[r][6] = b.z; q[r][7] = b.w;
+  }
+  u32 best[R], second[R];
+#pragma unroll
+  for (int r = 0; r < R; r++) best[r] = second[r] = KEY_INIT;
+
+  if (t1 > t0) {
+    cdesc_t* tr = (cdesc_t*)(uintptr_t)tbase + job.t_off;
+    const u32 last = t1 - 1;
+    u32 j = t0;
+    // Software-pipelined: two groups of two descriptors in SGPRs; the loads of
+    // one group are in flight while the other is consumed.  Indices past the
+    // range are clamped to `last` (loaded, never used).
+    u32x8 a0 = tr[min(j, last)], a1 = tr[min(j + 1, last)];
+    for (; j + 4 <= t1; j += 4) {
+      const u32x8 b0 = tr[j + 2], b1 = tr[j + 3];
+      update<R>(q, a0, j, best, second);
+      update<R>(q, a1, j + 1, best, second);
+      a0 = tr[min(j + 4, last)];
+      a1 = tr[min(j + 5, last)];
+      update<R>(q, b0, j + 2, best, second);
+      update<R>(q, b1, j + 3, best, second);
+    }
+    for (; j < t1; ++j) update<R>(q, tr[j], j, best, second);
+  }
+
+  uint2* out = scratch + (size_t)split * split_stride + job.out_off;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const u32 qi = q0 + r * 64 + lane;
+    if (qi < job.nq) out[qi] = make_uint2(best[r], second[r]);
+  }
+}
+
+// Exact merge of two partial (best key, second key) results over disjoint
+// train ranges: the two smallest of the union.
+__device__ __forceinline__ uint2 merge2(uint2 a, uint2 b) {
+  return make_uint2(min(a.x, b.x), min(min(a.y, b.y), max(a.x, b.x)));
+}
+
+__device__ __forceinline__ uint2 load_merged(const uint2* __restrict__ scratch, u32 off, u32 i,
+                                             u32 splits, u32 split_stride) {
+  uint2 v = scratch[off + i];
+  for (u32 s = 1; s < splits; s++) v = merge2(v, scratch[(size_t)s * split_stride + off + i]);
+  return v;
+}
+
+// keypoints.h:295-296: int(best) < threshold && dist_2_best*best <= second, plus
+// "best_match == -1 can never be emitted" (distance 256).
+__device__ __forceinline__ bool accepted(uint2 v, const uint16_t* lut, int threshold, u32& idx) {
+  const u32 d = v.x >> IDX_BITS;
+  const u32 s = min(v.y >> IDX_BITS, 256u);
+  idx = v.x & IDX_MASK;
+  return d < 256u && (int)d < threshold && s >= (u32)lut[d];
+}
+
+// Pair p of the chunk = jobs[2p] (forward: set 1 queries) and jobs[2p+1]
+// (backward).  Thread i decides whether (i, best1[i]) survives the cross-check.
+__device__ __forceinline__ bool cross_check(const uint2* __restrict__ scratch, const Job& f,
+                                            const Job& b, u32 i, u32 splits, u32 split_stride,
+                                            const uint16_t* lut, int threshold, u32& j) {
+  if (i >= f.nq) return false;
+  if (!accepted(load_merged(scratch, f.out_off, i, splits, split_stride), lut, threshold, j))
+    return false;
+  u32 back;
+  if (!accepted(load_merged(scratch, b.out_off, j, splits, split_stride), lut, threshold, back))
+    return false;
+  return back == i;
+}
+
+__device__ __forceinline__ void load_lut(uint16_t* lut, const AcceptParams& prm) {
+  for (u32 k = threadIdx.x; k < 257; k += blockDim.x) lut[k] = prm.min_second[k];
+  __syncthreads();
+}
+
+// counts[p] = number of matches of pair p.  One 256-thread workgroup per pair.
+__global__ __launch_bounds__(256) void count_kernel(const Job* __restrict__ jobs,
+                                                    const uint2* __restrict__ scratch, u32 splits,
+                                                    u32 split_stride, AcceptParams prm,
+                                                    u32* __restrict__ counts) {
+  __shared__ uint16_t lut[260];
+  __shared__ u32 total;
+  if (threadIdx.x == 0) total = 0;
+  load_lut(lut, prm);
+  const Job f = jobs[2 * blockIdx.x], b = jobs[2 * blockIdx.x + 1];
+  u32 mine = 0;
+  for (u32 i = threadIdx.x; i < f.nq; i += blockDim.x) {
+    u32 j;
+    mine += cross_check(scratch, f, b, i, splits, split_stride, lut, prm.threshold, j) ? 1u : 0u;
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+// Exclusive scan of the chunk's counts into global u64 offsets, continuing from
+// *running (the total of the previous chunks); writes offsets[first + k] and
+// finally *running = offsets[first + n].  Single 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict__ counts, u32 n,
+                                                           u64* __restrict__ offsets, u64 first,
+                                                           u64* __restrict__ running) {
+  __shared__ u64 wave_sum[16];
+  __shared__ u64 carry;
+  if (threadIdx.x == 0) carry = *running;
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (u32 base = 0; base < n; base += 1024) {
+    const u32 k = base + threadIdx.x;
+    const u64 v = k < n ? counts[k] : 0;
+    u64 inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const u64 up = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += up;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    u64 before = carry;
+    for (u32 w = 0; w < wave; w++) before += wave_sum[w];
+    if (k < n) offsets[first + k] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    offsets[first + n] = carry;
+    *running = carry;
+  }
+}
+
+// Writes pair p's matches, ascending in the first index (the reference's order,
+// keypoints.h:354-360), to out_pairs[offsets[first + p] ...); entries past
+// cap_pairs are dropped (the caller sees the needed total and gets
+// VSM_ERR_CAPACITY).  One 256-thread workgroup per pair.
+__global__ __launch_bounds__(256) void fill_kernel(const Job* __restrict__ jobs,
+                                                   const uint2* __restrict__ scratch, u32 splits,
+                                                   u32 split_stride, AcceptParams prm,
+                                                   const u64* __restrict__ offsets, u64 first,
+                                                   int2* __restrict__ out_pairs, u64 cap_pairs) {
+  __shared__ uint16_t lut[260];
+  __shared__ u32 wave_cnt[4];
+  load_lut(lut, prm);
+  const Job f = jobs[2 * blockIdx.x], b = jobs[2 * blockIdx.x + 1];
+  const u64 o0 = offsets[first + blockIdx.x];
+  if (offsets[first + blockIdx.x + 1] == o0) return;  // uniform: nothing to write
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 done = 0;
+  for (u32 base = 0; base < f.nq; base += 256) {
+    const u32 i = base + threadIdx.x;
+    u32 j = 0;
+    const bool hit = cross_check(scratch, f, b, i, splits, split_stride, lut, prm.threshold, j);
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = done, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
+    }
+    if (hit) {
+      const u64 pos = o0 + before + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      if (pos < cap_pairs) out_pairs[pos] = make_int2((int)i, (int)j);
+    }
+    done += all;
+    __syncthreads();
+  }
+}
+
+// jobs[2p], jobs[2p+1] for pair p = (pairs[p].x, pairs[p].y) of the database.
+// A pair naming an image >= n_img raises *bad and becomes an empty job pair.
+__global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
+                                  const u32* __restrict__ img_off, u32 n_img, u32 stride,
+                                  Job* __restrict__ jobs, u32* __restrict__ bad,
+                                  u64* __restrict__ comps) {
+  const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const uint2 pr = pairs[p];
+  Job f = {0, 0, 0, 0, p * 2 * stride, 0, 0, 0}, b = {0, 0, 0, 0, p * 2 * stride + stride, 0, 0, 0};
+  if (pr.x < n_img && pr.y < n_img) {
+    const u32 o1 = img_off[pr.x], n1 = img_off[pr.x + 1] - o1;
+    const u32 o2 = img_off[pr.y], n2 = img_off[pr.y + 1] - o2;
+    f.q_off = o1; f.nq = n1; f.t_off = o2; f.nt = n2;
+    b.q_off = o2; b.nq = n2; b.t_off = o1; b.nt = n1;
+    // comparisons the two scan jobs evaluate (both directions, keypoints.h:256-352)
+    if (n1 && n2) atomicAdd((unsigned long long*)comps, 2ull * n1 * n2);
+  } else {
+    atomicOr(bad, 1u);
+  }
+  jobs[2 * p] = f;
+  jobs[2 * p + 1] = b;
+}
+
+// Unpacks scan results (keypoints.h:259-262 conventions: idx -1 / 256 / 256
+// when nothing closer than 256 exists).
+__global__ void finalize_nn2_kernel(const uint2* __restrict__ scratch, u32 nq, u32 splits,
+                                    u32 split_stride, int* __restrict__ best_idx,
+                                    int* __restrict__ best_dist, int* __restrict__ second_dist) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint2 v = load_merged(scratch, 0, i, splits, split_stride);
+  const u32 d = v.x >> IDX_BITS;
+  best_idx[i] = d < 256u ? (int)(v.x & IDX_MASK) : -1;
+  best_dist[i] = (int)min(d, 256u);
+  second_dist[i] = (int)min(v.y >> IDX_BITS, 256u);
+}
+
+}  // namespace vsm

@@ -1,0 +1,218 @@
+"""Host-side mirror of the reference interface over the C ABI (include/vsmatch.h).
+
+``match_descriptors`` has the argument meaning of ``visnav::matchDescriptors``
+(/root/reference/include/visnav/keypoints.h:247-250); ``Matcher.match_pairs``
+is the batched form of the ``match_all`` loop (src/sfm.cpp:1295-1321).
+
+There is no CPU path here: if ``libvsmatch.so`` is missing or no MI355X is
+present, every call raises (``VsmError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsmatch.so")
+
+VSM_OK, VSM_ERR_INVALID, VSM_ERR_HIP, VSM_ERR_CAPACITY, VSM_ERR_NOMEM = range(5)
+VSM_MAX_SET = 1 << 23
+
+# every symbol include/vsmatch.h declares
+SYMBOLS = (
+    "vsm_version", "vsm_last_error", "vsm_create", "vsm_destroy", "vsm_stream",
+    "vsm_match_pair", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
+    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_set_profiling",
+    "vsm_set_variant",
+)
+
+
+class VsmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libvsmatch error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+_lib_lock = threading.Lock()
+_vp = C.c_void_p
+_sz = C.c_size_t
+
+
+def lib():
+    """Loads libvsmatch.so (built by __graft_entry__.build()); raises if absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise VsmError(VSM_ERR_HIP, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            L = C.CDLL(LIB_PATH)
+            L.vsm_version.restype = C.c_int
+            L.vsm_last_error.restype = C.c_char_p
+            L.vsm_create.argtypes = [C.c_int, C.POINTER(_vp)]
+            L.vsm_destroy.argtypes = [_vp]
+            L.vsm_destroy.restype = None
+            L.vsm_stream.argtypes = [_vp]
+            L.vsm_stream.restype = _vp
+            L.vsm_match_pair.argtypes = [_vp, _vp, _sz, _vp, _sz, C.c_int, C.c_double, _vp, _sz, C.POINTER(_sz)]
+            L.vsm_nn2.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]
+            L.vsm_nn2_device.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]
+            L.vsm_db_upload.argtypes = [_vp, _vp, _vp, _sz]
+            L.vsm_db_attach.argtypes = [_vp, _vp, _vp, _sz]
+            L.vsm_match_pairs.argtypes = [_vp, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz, C.POINTER(_sz)]
+            L.vsm_match_pairs_device.argtypes = [_vp, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz, C.POINTER(_sz)]
+            L.vsm_last_scan_stats.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            L.vsm_set_profiling.argtypes = [_vp, C.c_int]
+            L.vsm_set_variant.argtypes = [_vp, C.c_int]
+            _lib = L
+    return _lib
+
+
+def _check(rc, allow=()):
+    if rc != VSM_OK and rc not in allow:
+        raise VsmError(rc, lib().vsm_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def as_descriptors(a) -> np.ndarray:
+    """uint64[n, 4] C-contiguous view/copy of packed descriptors."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        if a.size % 4:
+            raise ValueError("descriptor array length must be a multiple of 4 uint64 words")
+        a = a.reshape(-1, 4)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError(f"descriptors must be uint64[n, 4], got {a.shape}")
+    return a
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a.size else C.c_void_p(0)
+
+
+class Matcher:
+    """One vsm_ctx = one GPU + one HIP stream + library-owned device scratch."""
+
+    def __init__(self, device: int = 0):
+        self._h = _vp()
+        _check(lib().vsm_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self._offsets = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().vsm_destroy(self._h)
+            self._h = _vp()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def stream(self) -> int:
+        return lib().vsm_stream(self._h) or 0
+
+    # -- keypoints.h:247-250 ------------------------------------------------
+    def match(self, d1, d2, threshold: int = 70, dist_2_best: float = 1.2) -> np.ndarray:
+        """visnav::matchDescriptors on one pair -> int32[n_matches, 2]."""
+        d1, d2 = as_descriptors(d1), as_descriptors(d2)
+        cap = max(1, min(len(d1), len(d2)))
+        out = np.empty((cap, 2), dtype=np.int32)
+        n = _sz(0)
+        _check(lib().vsm_match_pair(self._h, _ptr(d1), len(d1), _ptr(d2), len(d2), int(threshold),
+                                    float(dist_2_best), _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    # -- keypoints.h:256-290 --------------------------------------------------
+    def nn2(self, query, train):
+        """(best_idx, best_dist, second_dist), int32[nq] each."""
+        q, t = as_descriptors(query), as_descriptors(train)
+        bi = np.empty(len(q), dtype=np.int32)
+        bd = np.empty(len(q), dtype=np.int32)
+        sd = np.empty(len(q), dtype=np.int32)
+        _check(lib().vsm_nn2(self._h, _ptr(q), len(q), _ptr(t), len(t), _ptr(bi), _ptr(bd), _ptr(sd)))
+        return bi, bd, sd
+
+    def nn2_device(self, d_query: int, nq: int, d_train: int, nt: int, d_best_idx: int,
+                   d_best_dist: int, d_second_dist: int):
+        """Raw device pointers (e.g. torch tensors' data_ptr()); asynchronous."""
+        _check(lib().vsm_nn2_device(self._h, _vp(d_query), nq, _vp(d_train), nt, _vp(d_best_idx),
+                                    _vp(d_best_dist), _vp(d_second_dist)))
+
+    # -- src/sfm.cpp:1191-1214 feature_corners, flattened ---------------------
+    def db_upload(self, desc, offsets):
+        desc = as_descriptors(desc)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        if offsets.ndim != 1 or len(offsets) < 1 or int(offsets[-1]) != len(desc):
+            raise ValueError("offsets must be uint32[n_img+1] ending at len(desc)")
+        _check(lib().vsm_db_upload(self._h, _ptr(desc), _ptr(offsets), len(offsets) - 1))
+        self._offsets = offsets
+
+    def db_attach(self, d_desc: int, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        _check(lib().vsm_db_attach(self._h, _vp(d_desc), _ptr(offsets), len(offsets) - 1))
+        self._offsets = offsets
+
+    # -- src/sfm.cpp:1295-1321 ------------------------------------------------
+    def match_pairs(self, pairs, threshold: int = 70, dist_2_best: float = 1.2, cap: int | None = None):
+        """All pairs at once -> (offsets uint64[n+1], matches int32[total, 2]);
+        pair k's list is matches[offsets[k]:offsets[k+1]]."""
+        if self._offsets is None:
+            raise VsmError(VSM_ERR_INVALID, "no database uploaded")
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        n = len(pairs)
+        if cap is None:
+            sizes = np.diff(self._offsets.astype(np.int64))
+            ok = (pairs < len(sizes)).all(axis=1) if n else np.zeros(0, bool)
+            cap = int(np.minimum(sizes[pairs[ok, 0]], sizes[pairs[ok, 1]]).sum()) if n else 0
+        cap = max(int(cap), 1)
+        offs = np.empty(n + 1, dtype=np.uint64)
+        out = np.empty((cap, 2), dtype=np.int32)
+        total = _sz(0)
+        _check(lib().vsm_match_pairs(self._h, _ptr(pairs), n, int(threshold), float(dist_2_best),
+                                     _ptr(offs), _ptr(out), cap, C.byref(total)))
+        return offs, out[: total.value].copy()
+
+    def match_pairs_device(self, d_pairs: int, n_pairs: int, threshold: int, dist_2_best: float,
+                           d_out_offsets: int, d_out_pairs: int, cap: int) -> int:
+        """Everything device resident; returns the total number of matches.
+        Raises VsmError(VSM_ERR_CAPACITY) if it exceeds `cap`."""
+        total = _sz(0)
+        _check(lib().vsm_match_pairs_device(self._h, _vp(d_pairs), n_pairs, int(threshold),
+                                            float(dist_2_best), _vp(d_out_offsets), _vp(d_out_pairs),
+                                            int(cap), C.byref(total)))
+        return total.value
+
+    # -- measurement ------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        _check(lib().vsm_set_profiling(self._h, 1 if on else 0))
+
+    def set_variant(self, v: int):
+        _check(lib().vsm_set_variant(self._h, int(v)))
+
+    def last_scan_stats(self):
+        ms, n, comps = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().vsm_last_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(comps)))
+        return {"scan_ms": ms.value, "launches": n.value, "comparisons": comps.value}
+
+
+_default = threading.local()
+
+
+def match_descriptors(corner_descriptors_1, corner_descriptors_2, threshold: int, dist_2_best: float,
+                      device: int = 0) -> np.ndarray:
+    """Drop-in for visnav::matchDescriptors (keypoints.h:247-250): returns the
+    `matches` vector as int32[n, 2].  Uses one context per calling thread, so it
+    is re-entrant the way the reference's callers need (sfm.cpp:1295)."""
+    m = getattr(_default, "m", None)
+    if m is None or m.device != device:
+        m = Matcher(device)
+        _default.m = m
+    return m.match(corner_descriptors_1, corner_descriptors_2, threshold, dist_2_best)
