@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the descriptor-matching hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+Workload (BASELINE.json config 5, "Synthetic SfM: 5000 images x 2000
+descriptors all-pairs with cross-check"): a database of --images images of
+--desc synthetic ORB-like 256-bit descriptors (planted matches, duplicates and
+ratio-test failures, visual-slam_amd/synth.py) is resident in HBM on every rank
+(rank 0 generates it, one RCCL broadcast replicates it).  A step = one batch of
+--pairs image pairs per rank taken block-cyclically from the all-pairs list
+(src/sfm.cpp:1285-1290), each matched exactly like visnav::matchDescriptors
+(both directions + cross-check, threshold 70, ratio 1.2) into device-resident
+match lists.  Weak scaling: the per-rank batch is fixed.
+
+value = reference-equivalent 256-bit Hamming comparisons per second over all
+ranks (2*N1*N2 per pair, what keypoints.h:256-352 evaluates), in G comps/s;
+`pairs_per_s` is the same run in image pairs per second.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# BASELINE.md §4 / SURVEY.md §8d roofline denominator: 1 comparison = 8 v_xor_b32 +
+# 8 v_bcnt_u32_b32 = 16 int32 VALU lane-ops; peak = CUs x 64 lanes/clk x 2.4 GHz.
+LANE_OPS_PER_COMP = 16
+PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12  # 39.32 T lane-ops/s  (= 2.4576 T comps/s)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images", type=int, default=5000)
+    ap.add_argument("--desc", type=int, default=2000)
+    ap.add_argument("--pairs", type=int, default=32768, help="image pairs per rank per step")
+    ap.add_argument("--threshold", type=int, default=70)
+    ap.add_argument("--ratio", type=float, default=1.2)
+    ap.add_argument("--seed", type=int, default=2025)
+    ap.add_argument("--cpu-pairs", type=int, default=16384, help="CPU baseline sample (pairs); 0 = skip")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-extra", action="store_true", help="skip the stereo-latency and 1M x 1M extras")
+    ap.add_argument("--variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(db, off, pairs, thr, ratio, n_threads, gpu_lists):
+    """Times the CPU path on the host cores on a bounded sample of the same
+    pairs; checks the GPU lists against it (bit-exact)."""
+    from oracle import binding
+    impl = binding.ref() or binding.port()
+    n = len(pairs)
+    cap = int(np.diff(off.astype(np.int64)).max())
+    results = [None] * n
+    nxt = [0]
+    lock = threading.Lock()
+
+    def worker():
+        buf = np.empty((max(cap, 1), 2), np.int32)
+        while True:
+            with lock:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= n:
+                return
+            c = impl.match_db_pair(db, off, pairs[k, 0], pairs[k, 1], thr, ratio, buf)
+            results[k] = buf[:c].copy()
+
+    # single thread, small sample
+    n1 = max(1, min(n, 32))
+    t0 = time.perf_counter()
+    buf = np.empty((max(cap, 1), 2), np.int32)
+    for k in range(n1):
+        impl.match_db_pair(db, off, pairs[k, 0], pairs[k, 1], thr, ratio, buf)
+    t_single = (time.perf_counter() - t0) / n1
+    # all threads
+    ths = [threading.Thread(target=worker) for _ in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    sizes = np.diff(off.astype(np.int64))
+    comps = float((2 * sizes[pairs[:, 0]] * sizes[pairs[:, 1]]).sum())
+    ok = all(np.array_equal(results[k], gpu_lists[k]) for k in range(n))
+    comps_single = comps / n
+    return {
+        "value": comps / dt / 1e9, "unit": "Gcomp/s", "cores": n_threads, "kind": impl.kind,
+        "sample": f"{n} image pairs of the same database, {n_threads} threads over pairs "
+                  f"(the reference's tbb::parallel_for decomposition, sfm.cpp:1295), {dt:.1f} s",
+        "pairs_per_s": n / dt,
+        "single_thread_gcomps": comps_single / t_single / 1e9,
+        "single_thread_ms_per_pair": t_single * 1e3,
+        "gpu_lists_bit_exact": bool(ok),
+    }
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    vsm = importlib.import_module("visual-slam_amd")
+    sfm_pairs = importlib.import_module("visual-slam_amd.sfm_pairs")
+    synth = vsm.synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- database: rank 0 generates, one broadcast replicates (RCCL over xGMI) -------------
+    t_gen = time.perf_counter()
+    if rank == 0:
+        db, off = synth.sfm_database(a.images, a.desc, a.seed, share_frac=0.4, window=8)
+    else:
+        db, off = None, None
+    t_gen = time.perf_counter() - t_gen
+    t_bc = time.perf_counter()
+    if world > 1:
+        d_db, off = sfm_pairs.broadcast_database(db, off, dev)
+        torch.cuda.synchronize()
+    else:
+        d_db = torch.from_numpy(db.view(np.int64)).to(dev)
+    t_bc = time.perf_counter() - t_bc
+
+    m = vsm.Matcher(local)
+    m.set_variant(a.variant)
+    m.db_attach(d_db.data_ptr(), off)
+
+    # ---- pairs: canonical all-pairs list, block-cyclic over ranks -----------------------------
+    n_img = a.images
+    total_pairs = n_img * (n_img - 1) // 2
+    P = min(a.pairs, max(1, total_pairs // world))
+    n_steps = a.warmup + a.steps
+
+    def pair_of(k):  # k-th pair of the (i, j<i) enumeration, vectorised
+        k = np.asarray(k, dtype=np.int64)
+        i = np.floor((1 + np.sqrt(1 + 8 * k.astype(np.float64))) / 2).astype(np.int64)
+        i = np.where(i * (i - 1) // 2 > k, i - 1, i)
+        i = np.where((i + 1) * i // 2 <= k, i + 1, i)
+        j = k - i * (i - 1) // 2
+        return np.stack([i, j], axis=1).astype(np.uint32)
+
+    step_pairs = []
+    for s in range(n_steps):
+        first = ((s * world + rank) * P) % max(1, total_pairs - P + 1)
+        step_pairs.append(pair_of(np.arange(first, first + P)))
+    d_pairs = [torch.from_numpy(p.view(np.int32).copy()).to(dev) for p in step_pairs]
+    cap = P * a.desc
+    d_offsets = torch.empty(P + 1, dtype=torch.int64, device=dev)
+    d_out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    sizes = np.diff(off.astype(np.int64))
+
+    def run(s):
+        return m.match_pairs_device(d_pairs[s].data_ptr(), P, a.threshold, a.ratio,
+                                    d_offsets.data_ptr(), d_out.data_ptr(), cap)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(a.warmup):
+        run(s)
+    m.set_profiling(True)
+    scan_ms, scan_launches, scan_comps, matches = 0.0, 0, 0, 0
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(a.warmup, n_steps):
+        matches += run(s)
+        st = m.last_scan_stats()
+        scan_ms += st["scan_ms"]
+        scan_launches += st["launches"]
+        scan_comps += st["comparisons"]
+    barrier()
+    dt = time.perf_counter() - t0
+    m.set_profiling(False)
+
+    comps_rank = float(sum((2 * sizes[p[:, 0]] * sizes[p[:, 1]]).sum() for p in step_pairs[a.warmup:]))
+    stats = torch.tensor([dt, comps_rank, float(P * a.steps), float(matches)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+    comps_all, pairs_all, matches_all = float(stats[1]), float(stats[2]), float(stats[3])
+
+    # ---- gather of the last step's lists to rank 0 (reported separately, not in `value`) -----
+    gather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tg = time.perf_counter()
+        offs_h = d_offsets.cpu().numpy().astype(np.uint64)
+        lists_h = d_out[: int(offs_h[-1])].cpu().numpy()
+        sfm_pairs.gather_matches(np.arange(P, dtype=np.int64) + rank * P, offs_h, lists_h, P * world, dev)
+        dist.barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- rank 0: roofline, CPU baseline, extras -----------------------------------------------------
+    assert scan_comps == comps_rank, (scan_comps, comps_rank)
+    achieved = scan_comps * LANE_OPS_PER_COMP / (scan_ms * 1e-3) / 1e12
+    roofline = {
+        "bound": "valu", "kernel": "scan_kernel<4>",
+        "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlaneop/s", "frac": achieved / PEAK_TLANEOPS,
+        "traffic": None,
+        "launches": scan_launches, "avg_launch_ms": scan_ms / max(1, scan_launches),
+        "algorithmic": "16 int32 VALU lane-ops (8 v_xor_b32 + 8 v_bcnt_u32_b32) per 256-bit comparison x "
+                       "comparisons evaluated per launch; peak = 256 CUs x 64 lanes/clk x 2.4 GHz (BASELINE.md §4)",
+        "kernel_gcomps": scan_comps / (scan_ms * 1e-3) / 1e9,
+        "hbm_algorithmic_bytes_per_pair": int(32 * 2 * a.desc),
+    }
+    out = {
+        "metric": "hamming_comparisons_per_sec", "value": comps_all / dt / 1e9, "unit": "Gcomp/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": "sfm_allpairs_crosscheck", "images": a.images, "desc_per_image": a.desc,
+                   "pairs_per_rank_per_step": P, "threshold": a.threshold, "dist_2_best": a.ratio,
+                   "sharding": f"pairs block-cyclic over {world} rank(s), database replicated"},
+        "pairs_per_s": pairs_all / dt, "matches_per_step": matches_all / a.steps,
+        "roofline": roofline,
+        "setup": {"db_generate_s": t_gen, "db_broadcast_or_upload_s": t_bc, "gather_last_step_ms": gather_ms},
+    }
+
+    if a.cpu_pairs > 0 and world == 1:
+        n_cpu = min(a.cpu_pairs, P)
+        s = n_steps - 1
+        offs_h = d_offsets[: n_cpu + 1].cpu().numpy()
+        lists_h = d_out[: int(offs_h[-1])].cpu().numpy()
+        gpu_lists = [lists_h[int(offs_h[k]): int(offs_h[k + 1])] for k in range(n_cpu)]
+        out["cpu_baseline"] = cpu_baseline(db, off, step_pairs[s][:n_cpu], a.threshold, a.ratio,
+                                           a.cpu_threads, gpu_lists)
+    else:
+        out["cpu_baseline"] = None
+
+    if not a.no_extra and world == 1:
+        extra = {}
+        # config 2: one stereo pair, ~1500 keypoints per frame (odometry.cpp:814), host pointers in/out
+        l, r = synth.orb_like_pair(1500, 1500, a.seed + 1)
+        for _ in range(5):
+            res = m.match(l, r, a.threshold, a.ratio)
+        t = time.perf_counter()
+        reps = 50
+        for _ in range(reps):
+            res = m.match(l, r, a.threshold, a.ratio)
+        lat = (time.perf_counter() - t) / reps
+        extra["stereo_1500x1500"] = {"latency_ms_host_to_host": lat * 1e3, "matches": int(len(res)),
+                                     "gcomps": 2 * 1500 * 1500 / lat / 1e9}
+        # config 4: 1M x 1M one direction (1-NN + ratio test inputs), device resident
+        n = 1 << 20
+        qa, tb = synth.planted_sets(n, a.seed + 2)
+        dq = torch.from_numpy(qa.view(np.int64)).to(dev)
+        dtb = torch.from_numpy(tb.view(np.int64)).to(dev)
+        o = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
+        m.set_profiling(True)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        m.nn2_device(dq.data_ptr(), n, dtb.data_ptr(), n, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t
+        st = m.last_scan_stats()
+        m.set_profiling(False)
+        bd, sd = o[1].cpu().numpy(), o[2].cpu().numpy()
+        extra["nn2_1Mx1M"] = {"seconds": t, "gcomps": n * n / t / 1e9, "kernel_ms": st["scan_ms"],
+                              "roofline_frac": n * float(n) * 16 / (st["scan_ms"] * 1e-3) / 1e12 / PEAK_TLANEOPS,
+                              "accepted_thr70_ratio1.2": int(((bd < 70) & (1.2 * bd <= sd)).sum())}
+        out["extra"] = extra
+
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

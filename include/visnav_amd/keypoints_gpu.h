@@ -1,0 +1,122 @@
+// keypoints_gpu.h -- header-only C++ shim with the reference's exact signature.
+//
+// Drop-in for the definition at /root/reference/include/visnav/keypoints.h:247-361:
+//
+//   void visnav::matchDescriptors(
+//       const std::vector<std::bitset<256>>& corner_descriptors_1,
+//       const std::vector<std::bitset<256>>& corner_descriptors_2,
+//       std::vector<std::pair<int, int>>& matches, int threshold, double dist_2_best);
+//
+// Same argument meaning and output (matches is cleared, then filled in the
+// reference's order); the work runs on an MI355X through the C ABI of
+// libvsmatch.so (include/vsmatch.h).  The reference function has no error path;
+// this one throws std::runtime_error when the GPU path fails -- there is no CPU
+// fallback.  Re-entrant: one library context per calling thread, as the
+// tbb::parallel_for callers need (src/sfm.cpp:1295-1321, 1397-1423).
+//
+// The device is taken from the environment variable VSM_DEVICE (default 0).
+#pragma once
+
+#include <bitset>
+#include <cstdint>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "vsmatch.h"
+
+namespace visnav {
+namespace vsm_detail {
+
+static_assert(sizeof(std::bitset<256>) == 32, "std::bitset<256> must be four packed 64-bit words");
+static_assert(sizeof(std::pair<int, int>) == 8, "std::pair<int,int> must be two packed int32");
+
+struct ThreadContext {
+  vsm_ctx* ctx = nullptr;
+  ~ThreadContext() {
+    if (ctx) vsm_destroy(ctx);
+  }
+};
+
+inline vsm_ctx* thread_context() {
+  thread_local ThreadContext t;
+  if (!t.ctx) {
+    // bit k of the bitset must be bit k%64 of word k/64 (libstdc++, libc++)
+    std::bitset<256> probe;
+    probe.set(0);
+    probe.set(255);
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(&probe);
+    if (w[0] != 1ull || w[3] != (1ull << 63))
+      throw std::runtime_error("visnav::matchDescriptors (GPU): unexpected std::bitset<256> layout");
+    const char* dev = std::getenv("VSM_DEVICE");
+    if (vsm_create(dev ? std::atoi(dev) : 0, &t.ctx) != VSM_OK)
+      throw std::runtime_error(std::string("visnav::matchDescriptors (GPU): ") + vsm_last_error());
+  }
+  return t.ctx;
+}
+
+}  // namespace vsm_detail
+
+inline void matchDescriptors(const std::vector<std::bitset<256>>& corner_descriptors_1,
+                             const std::vector<std::bitset<256>>& corner_descriptors_2,
+                             std::vector<std::pair<int, int>>& matches, int threshold,
+                             double dist_2_best) {
+  matches.clear();  // keypoints.h:251
+  const size_t n1 = corner_descriptors_1.size(), n2 = corner_descriptors_2.size();
+  if (n1 == 0 || n2 == 0) return;
+  const size_t cap = n1 < n2 ? n1 : n2;  // the cross-check emits at most min(n1, n2) pairs
+  matches.resize(cap);
+  size_t count = 0;
+  const int rc = vsm_match_pair(
+      vsm_detail::thread_context(), reinterpret_cast<const uint64_t*>(corner_descriptors_1.data()), n1,
+      reinterpret_cast<const uint64_t*>(corner_descriptors_2.data()), n2, threshold, dist_2_best,
+      reinterpret_cast<int32_t*>(matches.data()), cap, &count);
+  if (rc != VSM_OK) {
+    matches.clear();
+    throw std::runtime_error(std::string("visnav::matchDescriptors (GPU): ") + vsm_last_error());
+  }
+  matches.resize(count);
+}
+
+// The loop of match_all / match_bow (src/sfm.cpp:1295-1321, 1397-1423) as one
+// batch: out[k] = matchDescriptors(*sets[ids_to_match[k].first],
+// *sets[ids_to_match[k].second], ...).  The descriptor sets are uploaded once
+// and every pair is matched on the GPU in one call.
+inline void matchDescriptorsBatch(const std::vector<const std::vector<std::bitset<256>>*>& sets,
+                                  const std::vector<std::pair<int, int>>& ids_to_match,
+                                  std::vector<std::vector<std::pair<int, int>>>& out, int threshold,
+                                  double dist_2_best) {
+  out.assign(ids_to_match.size(), {});
+  std::vector<uint32_t> offsets(sets.size() + 1, 0);
+  for (size_t i = 0; i < sets.size(); i++) offsets[i + 1] = offsets[i] + uint32_t(sets[i]->size());
+  std::vector<uint64_t> flat(size_t(offsets.back()) * 4);
+  for (size_t i = 0; i < sets.size(); i++)
+    if (!sets[i]->empty())
+      std::copy(reinterpret_cast<const uint64_t*>(sets[i]->data()),
+                reinterpret_cast<const uint64_t*>(sets[i]->data()) + sets[i]->size() * 4,
+                flat.begin() + size_t(offsets[i]) * 4);
+  std::vector<uint32_t> pairs(ids_to_match.size() * 2);
+  size_t cap = 0;
+  for (size_t k = 0; k < ids_to_match.size(); k++) {
+    const int a = ids_to_match[k].first, b = ids_to_match[k].second;
+    if (a < 0 || b < 0 || size_t(a) >= sets.size() || size_t(b) >= sets.size())
+      throw std::runtime_error("visnav::matchDescriptorsBatch: image index out of range");
+    pairs[2 * k] = uint32_t(a);
+    pairs[2 * k + 1] = uint32_t(b);
+    cap += std::min(sets[a]->size(), sets[b]->size());
+  }
+  vsm_ctx* ctx = vsm_detail::thread_context();
+  std::vector<uint64_t> offs(ids_to_match.size() + 1);
+  std::vector<std::pair<int, int>> all(cap ? cap : 1);
+  size_t total = 0;
+  if (vsm_db_upload(ctx, flat.data(), offsets.data(), sets.size()) != VSM_OK ||
+      vsm_match_pairs(ctx, pairs.data(), ids_to_match.size(), threshold, dist_2_best, offs.data(),
+                      reinterpret_cast<int32_t*>(all.data()), all.size(), &total) != VSM_OK)
+    throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPU): ") + vsm_last_error());
+  for (size_t k = 0; k < ids_to_match.size(); k++)
+    out[k].assign(all.begin() + offs[k], all.begin() + offs[k + 1]);
+}
+
+}  // namespace visnav

@@ -130,3 +130,16 @@ def test_property_swap_transposes(m):
     assert len(ab) > 500
     assert sorted(map(tuple, ab.tolist())) == sorted((y, x) for x, y in ba.tolist())
     assert np.all(np.diff(ab[:, 0]) > 0) and np.all(np.diff(ba[:, 0]) > 0)
+
+
+def test_cpp_shim_reference_signature():
+    """visnav::matchDescriptors with the reference's C++ signature (keypoints.h:247-250),
+    std::bitset in / std::pair out, concurrent callers; binary built by build()."""
+    import subprocess
+    root = os.path.dirname(cases.GOLDEN.rstrip("/"))
+    exe = os.path.join(root, "cpp", "shim_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    g = cases.GOLDEN
+    r = subprocess.run([exe, os.path.join(g, "ex3_kd0.npy"), os.path.join(g, "ex3_kd1.npy"),
+                        os.path.join(g, "ex3_matches.npy")], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -1,0 +1,91 @@
+"""The N>1 path (block-cyclic pair sharding, database broadcast, result gather)
+on CPU with the gloo backend, world_size 2 and 3.  The per-rank matcher is the
+oracle here (tests may use it); on GPUs it is the HIP path."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import binding
+from tests import cases
+
+sfm_pairs = importlib.import_module("visual-slam_amd.sfm_pairs")
+
+
+def _oracle_match_pairs(desc, offsets, pairs, threshold, dist_2_best):
+    offs = [0]
+    out = []
+    for (i, j) in np.asarray(pairs).tolist():
+        r = binding.port().match(desc[offsets[i]:offsets[i + 1]], desc[offsets[j]:offsets[j + 1]],
+                                 threshold, dist_2_best)
+        out.append(r)
+        offs.append(offs[-1] + len(r))
+    flat = np.concatenate(out) if out else np.zeros((0, 2), np.int32)
+    return np.array(offs, dtype=np.uint64), flat
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        db, off, pairs = cases.sfm_small()
+        # only rank 0 "loads" the database; the others receive it by broadcast
+        d_t, off_b = sfm_pairs.broadcast_database(db if rank == 0 else None, off if rank == 0 else None, "cpu")
+        db_b = d_t.numpy().view(np.uint64)
+        assert np.array_equal(db_b, db) and np.array_equal(off_b, off)
+        res = sfm_pairs.match_all_sharded(db_b, off_b, pairs, 70, 1.2, device="cpu",
+                                          match_pairs_fn=_oracle_match_pairs, block=2)
+        if rank == 0:
+            q.put((res[0].tolist(), res[1].tolist()))
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_match_all_equals_single_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    offs, flat = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    db, off, pairs = cases.sfm_small()
+    want_off, want = _oracle_match_pairs(db, off, pairs, 70, 1.2)
+    assert offs == want_off.tolist()
+    assert flat == want.tolist()
+
+
+def test_shard_indices_partition():
+    for n, world, block in [(0, 2, 4), (1, 8, 4096), (10, 3, 2), (13284, 8, 4096), (100000, 8, 4096)]:
+        parts = [sfm_pairs.shard_indices(n, r, world, block) for r in range(world)]
+        allidx = np.sort(np.concatenate(parts))
+        assert np.array_equal(allidx, np.arange(n))
+        if n >= world * block * 4:
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= block
+
+
+def test_pair_enumeration_matches_sfm_rule():
+    """sfm.cpp:1285-1290: j < i, different frame ids; 164 images of 82 stereo frames -> 13284."""
+    frame = np.repeat(np.arange(82), 2)
+    pairs = cases.synth.all_pairs(164, frame)
+    assert len(pairs) == 13284
+    assert np.all(pairs[:, 1] < pairs[:, 0])
+    assert np.all(frame[pairs[:, 0]] != frame[pairs[:, 1]])

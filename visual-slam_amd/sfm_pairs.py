@@ -1,0 +1,129 @@
+"""All-image-pair matching across the GPUs of one node.
+
+Mirrors ``match_all`` of the reference (src/sfm.cpp:1276-1353): enumerate the
+pairs (1285-1290), match every pair, collect the per-pair lists.  The reference
+parallelises over pairs with ``tbb::parallel_for`` (1295); here the pair list
+is cut block-cyclically over ranks (one process per GPU), the descriptor
+database is replicated with ONE broadcast (RCCL over xGMI; ``backend="nccl"``
+is RCCL on ROCm) and there is no communication while matching.  The result
+lists are gathered to rank 0 afterwards (counts first, then the flat lists).
+
+The per-rank matcher is injected (`match_pairs_fn`) so that the sharding and
+gathering logic can be exercised on CPU with the gloo backend; the default is
+the HIP path and it raises if the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .synth import all_pairs  # noqa: F401  (sfm.cpp:1285-1290)
+
+BLOCK = 4096  # pairs per block of the block-cyclic partition
+
+
+def shard_indices(n_pairs: int, rank: int, world: int, block: int = BLOCK) -> np.ndarray:
+    """Indices (into the canonical pair list) owned by `rank`: blocks of `block`
+    consecutive pairs dealt round-robin.  Consecutive pairs share an image, so a
+    block keeps that image's descriptors hot in the XCD L2s."""
+    idx = np.arange(n_pairs, dtype=np.int64)
+    return idx[(idx // block) % world == rank]
+
+
+def broadcast_database(desc: np.ndarray | None, offsets: np.ndarray | None, device, group=None, src: int = 0):
+    """Replicates (desc uint64[n,4], offsets uint32[n_img+1]) from `src` to every
+    rank: one broadcast of sizes, one of offsets, one of the descriptors.
+    Returns (desc_tensor on `device` as int64[n,4], offsets ndarray)."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if rank == src:
+        meta[0], meta[1] = desc.shape[0], offsets.shape[0]
+    dist.broadcast(meta, src, group=group)
+    n, n_off = int(meta[0]), int(meta[1])
+    off_t = torch.zeros(n_off, dtype=torch.int64, device=device)
+    d_t = torch.empty((n, 4), dtype=torch.int64, device=device)
+    if rank == src:
+        off_t.copy_(torch.from_numpy(offsets.astype(np.int64)))
+        d_t.copy_(torch.from_numpy(np.ascontiguousarray(desc).view(np.int64)))
+    dist.broadcast(off_t, src, group=group)
+    dist.broadcast(d_t, src, group=group)
+    return d_t, off_t.cpu().numpy().astype(np.uint32)
+
+
+def gather_matches(local_idx: np.ndarray, local_offsets: np.ndarray, local_matches: np.ndarray,
+                   n_pairs: int, device, group=None, dst: int = 0):
+    """Gathers every rank's per-pair lists to `dst` in canonical pair order.
+    Returns (offsets uint64[n_pairs+1], matches int32[total,2]) on dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts = np.diff(local_offsets.astype(np.int64))
+    sizes = torch.tensor([len(local_idx), len(local_matches)], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = [tuple(int(v) for v in s.cpu()) for s in all_sizes]
+    max_p = max(1, max(s[0] for s in all_sizes))
+    max_m = max(1, max(s[1] for s in all_sizes))
+    # padded payloads: [pair indices | counts] and the flat match list
+    head = torch.zeros(2 * max_p, dtype=torch.int64, device=device)
+    head[: len(local_idx)] = torch.from_numpy(local_idx.astype(np.int64))
+    head[max_p: max_p + len(counts)] = torch.from_numpy(counts)
+    body = torch.zeros((max_m, 2), dtype=torch.int32, device=device)
+    if len(local_matches):
+        body[: len(local_matches)] = torch.from_numpy(np.ascontiguousarray(local_matches, dtype=np.int32))
+    heads = [torch.zeros_like(head) for _ in range(world)] if rank == dst else None
+    bodies = [torch.zeros_like(body) for _ in range(world)] if rank == dst else None
+    dist.gather(head, heads, dst=dst, group=group)
+    dist.gather(body, bodies, dst=dst, group=group)
+    if rank != dst:
+        return None
+    cnt = np.zeros(n_pairs, dtype=np.int64)
+    where = {}
+    for r in range(world):
+        p, m = all_sizes[r]
+        h = heads[r].cpu().numpy()
+        idx, c = h[:p], h[max_p: max_p + p]
+        cnt[idx] = c
+        starts = np.concatenate([[0], np.cumsum(c)])[:-1]
+        where[r] = (idx, starts, c, bodies[r].cpu().numpy()[:m])
+    offsets = np.zeros(n_pairs + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(cnt)
+    out = np.empty((int(offsets[-1]), 2), dtype=np.int32)
+    for r in range(world):
+        idx, starts, c, body_r = where[r]
+        for k in range(len(idx)):
+            o = int(offsets[idx[k]])
+            out[o: o + c[k]] = body_r[starts[k]: starts[k] + c[k]]
+    return offsets, out
+
+
+def _hip_match_pairs(device_index: int):
+    from .matcher import Matcher
+    m = Matcher(device_index)
+
+    def run(desc, offsets, pairs, threshold, dist_2_best):
+        m.db_upload(desc, offsets)
+        return m.match_pairs(pairs, threshold, dist_2_best)
+
+    return run
+
+
+def match_all_sharded(desc, offsets, pairs, threshold: int = 70, dist_2_best: float = 1.2, group=None,
+                      device="cpu", match_pairs_fn=None, block: int = BLOCK):
+    """Every rank matches its block-cyclic share of `pairs`; rank 0 returns
+    (offsets, matches) for the whole list in canonical order, other ranks None.
+    `desc`/`offsets`/`pairs` must be identical on every rank (replicated
+    database, see broadcast_database).
+
+    `match_pairs_fn(desc, offsets, pairs, threshold, dist_2_best) -> (offsets, matches)`
+    defaults to the HIP path on this rank's GPU."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if match_pairs_fn is None:
+        import torch
+        match_pairs_fn = _hip_match_pairs(torch.cuda.current_device())
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    mine = shard_indices(len(pairs), rank, world, block)
+    loc_off, loc_matches = match_pairs_fn(desc, offsets, pairs[mine], threshold, dist_2_best)
+    return gather_matches(mine, np.asarray(loc_off), np.asarray(loc_matches), len(pairs), device, group)
