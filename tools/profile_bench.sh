@@ -1,0 +1,14 @@
+#!/bin/bash
+# Profiles bench.py's hot path with rocprofv3 on the GPU box (run through gpurun).
+# Pass 1: kernel trace + stats.  Passes 2-4: PMC counters, each in a run of its own.
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+OUT=gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+ARGS="bench.py --steps 3 --warmup 1 --no-extra --cpu-pairs 0 --pairs 16384"
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err
+timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- python3 $ARGS > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 $ARGS > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 $ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+find $OUT -type f | head -50

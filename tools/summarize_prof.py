@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 rocpd databases written by tools/profile_bench.sh into the
+text summaries committed under profiles/.  usage: summarize_prof.py <prof dir> <out dir>"""
+import os
+import sqlite3
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+
+
+def q(db, sql):
+    return sqlite3.connect(db).execute(sql).fetchall()
+
+
+with open(os.path.join(dst, "kernel_trace_stats.txt"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-extra --cpu-pairs 0 --pairs 16384\n")
+    f.write("# columns: kernel | calls | total_us | avg_us | percent\n")
+    for name, calls, total, avg, pct in q(os.path.join(src, "trace", "t_results.db"), "select * from top_kernels"):
+        f.write(f"{name.split('(')[0]:60s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:8.3f}\n")
+
+with open(os.path.join(dst, "pmc_counters.txt"), "w") as f:
+    f.write("# rocprofv3 --pmc <counters> (one run per group) -- same command; per-dispatch averages\n")
+    f.write("# columns: kernel | counter | dispatches | avg value per dispatch\n")
+    for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        p = os.path.join(src, d, "p_results.db")
+        if not os.path.exists(p):
+            continue
+        for name, ctr, n, avg in q(p, "select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                      "group by kernel_name, counter_name order by kernel_name, counter_name"):
+            f.write(f"{name.split('(')[0]:50s} {ctr:22s} {n:4d} {avg:20.1f}\n")
+print(open(os.path.join(dst, "kernel_trace_stats.txt")).read())
+print(open(os.path.join(dst, "pmc_counters.txt")).read())

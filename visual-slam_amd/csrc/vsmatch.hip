@@ -97,6 +97,8 @@ struct PinBuf {
 };
 
 constexpr size_t DESC_BYTES = 32;
+// v_mov filler behind every v_bcnt: +10 % on MI355X (profiles/r01/scan_variants.txt)
+constexpr int SCAN_FILL = 2;
 constexpr size_t SCRATCH_BUDGET = (size_t)2 << 30;  // scan results per chunk of pairs
 constexpr u32 TARGET_WAVES = 4096;                  // below this the train range is split
 
@@ -223,9 +225,9 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   const u32x4* q = (const u32x4*)qbase;
   const u32x4* t = (const u32x4*)tbase;
   switch (sh.R) {
-    case 1: hipLaunchKernelGGL(scan_kernel<1>, grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
-    case 4: hipLaunchKernelGGL(scan_kernel<4>, grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
-    case 8: hipLaunchKernelGGL(scan_kernel<8>, grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    case 1: hipLaunchKernelGGL((scan_kernel<1, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    case 4: hipLaunchKernelGGL((scan_kernel<4, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    case 8: hipLaunchKernelGGL((scan_kernel<8, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
   }
   HIP_TRY(hipGetLastError());

@@ -56,31 +56,60 @@ __device__ __forceinline__ u32 med3_u32(u32 a, u32 b, u32 c) {
 // popcount(x) + acc in one instruction (the accumulate operand of v_bcnt is free).
 // Written as asm because the compiler otherwise re-associates the eight counts
 // into v_bcnt(x, 0) + v_add3_u32 trees, three instructions more per comparison.
+//
+// FILL selects an issue-slot filler glued behind each v_bcnt (tools/valu_rate2:
+// on gfx950 a v_bcnt occupies the SIMD for ~4.4 cycles but a following s_nop /
+// v_mov of the same wave issues in its shadow, and the v_xor after that then
+// runs at the 2.3-cycle rate instead of 4.4):  0 none, 1 s_nop 0, 2 v_mov.
+template <int FILL>
 __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
   u32 r;
-  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  if (FILL == 1 || FILL == 4) asm("v_bcnt_u32_b32 %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(x), "v"(acc));
+  else if (FILL == 2 || FILL == 3) { u32 junk; asm("v_bcnt_u32_b32 %0, %2, %3\n\tv_mov_b32 %1, %2" : "=v"(r), "=&v"(junk) : "v"(x), "v"(acc)); }
+  else asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
   return r;
 }
+template <int FILL>
 __device__ __forceinline__ u32 bcnt0(u32 x) {
   u32 r;
-  asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+  if (FILL == 1 || FILL == 4) asm("v_bcnt_u32_b32 %0, %1, 0\n\ts_nop 0" : "=v"(r) : "v"(x));
+  else if (FILL == 2 || FILL == 3) { u32 junk; asm("v_bcnt_u32_b32 %0, %2, 0\n\tv_mov_b32 %1, %2" : "=v"(r), "=&v"(junk) : "v"(x)); }
+  else asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
   return r;
 }
 
 // One train descriptor (wave-uniform, in SGPRs) against the R query descriptors
 // each lane holds in VGPRs: 8 xor + 8 bcnt + key + med3 + min per comparison.
 // Invariant best <= second, so the new second is the median of (best, key, second).
-template <int R>
+template <int R, int FILL>
 __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 j, u32 (&best)[R],
                                        u32 (&second)[R]) {
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    u32 d = bcnt0(q[r][0] ^ t[0]);
+    u32 d = bcnt0<FILL>(q[r][0] ^ t[0]);
 #pragma unroll
-    for (int w = 1; w < 8; w++) d = bcnt_acc(q[r][w] ^ t[w], d);
-    const u32 key = (d << IDX_BITS) | j;
-    second[r] = med3_u32(best[r], key, second[r]);
-    best[r] = min(best[r], key);
+    for (int w = 1; w < 8; w++) d = bcnt_acc<FILL>(q[r][w] ^ t[w], d);
+    u32 key;
+    if (FILL >= 3) {
+      // fillers behind the three tracking instructions too (3: v_mov, 4: s_nop)
+      u32 junk, nb, ns;
+      if (FILL == 3)
+        asm("v_lshl_or_b32 %0, %4, 23, %5\n\tv_mov_b32 %3, %4\n\t"
+            "v_med3_u32 %1, %6, %0, %7\n\tv_mov_b32 %3, %4\n\t"
+            "v_min_u32 %2, %6, %0\n\tv_mov_b32 %3, %4"
+            : "=&v"(key), "=&v"(ns), "=&v"(nb), "=&v"(junk) : "v"(d), "s"(j), "v"(best[r]), "v"(second[r]));
+      else
+        asm("v_lshl_or_b32 %0, %3, 23, %4\n\ts_nop 0\n\t"
+            "v_med3_u32 %1, %5, %0, %6\n\ts_nop 0\n\t"
+            "v_min_u32 %2, %5, %0\n\ts_nop 0"
+            : "=&v"(key), "=&v"(ns), "=&v"(nb) : "v"(d), "s"(j), "v"(best[r]), "v"(second[r]));
+      second[r] = ns;
+      best[r] = nb;
+    } else {
+      key = (d << IDX_BITS) | j;
+      second[r] = med3_u32(best[r], key, second[r]);
+      best[r] = min(best[r], key);
+    }
   }
 }
 
@@ -93,7 +122,7 @@ typedef const __attribute__((address_space(4))) u32x8 cdesc_t;
 // queries q0 + r*64 + l, so every query load is a coalesced 2 KiB) and scans
 // its split of the train range.  Waves never communicate; there is no LDS and
 // no barrier in this kernel.
-template <int R>
+template <int R, int FILL = 0>
 __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qbase,
                                                    const u32x4* __restrict__ tbase,
                                                    const Job* __restrict__ jobs, u32 wgs_per_job,
@@ -134,14 +163,14 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
     u32x8 a0 = tr[min(j, last)], a1 = tr[min(j + 1, last)];
     for (; j + 4 <= t1; j += 4) {
       const u32x8 b0 = tr[j + 2], b1 = tr[j + 3];
-      update<R>(q, a0, j, best, second);
-      update<R>(q, a1, j + 1, best, second);
+      update<R, FILL>(q, a0, j, best, second);
+      update<R, FILL>(q, a1, j + 1, best, second);
       a0 = tr[min(j + 4, last)];
       a1 = tr[min(j + 5, last)];
-      update<R>(q, b0, j + 2, best, second);
-      update<R>(q, b1, j + 3, best, second);
+      update<R, FILL>(q, b0, j + 2, best, second);
+      update<R, FILL>(q, b1, j + 3, best, second);
     }
-    for (; j < t1; ++j) update<R>(q, tr[j], j, best, second);
+    for (; j < t1; ++j) update<R, FILL>(q, tr[j], j, best, second);
   }
 
   uint2* out = scratch + (size_t)split * split_stride + job.out_off;
