@@ -101,6 +101,7 @@ constexpr size_t DESC_BYTES = 32;
 constexpr int SCAN_FILL = 2;
 constexpr size_t SCRATCH_BUDGET = (size_t)2 << 30;  // scan results per chunk of pairs
 constexpr u32 TARGET_WAVES = 4096;                  // below this the train range is split
+constexpr u32 LONG_SCAN_WAVES = 98304;              // 16 x the 6144 resident waves of scan_kernel<4>
 
 }  // namespace
 
@@ -197,17 +198,21 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
   ScanShape s;
   const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256);
   s.R = waves_r4 >= TARGET_WAVES ? 4 : 1;
-  if (variant == 1) s.R = 1;
-  if (variant == 4) s.R = 4;
-  if (variant == 8) s.R = 8;
+  // experiment knob (vsm_set_variant): low byte = R override, next byte = splits override
+  const int vr = variant & 0xff, vs = (variant >> 8) & 0xff;
+  if (vr == 1 || vr == 4 || vr == 8) s.R = vr;
   const u32 tq = 64 * s.R;
   const u32 tiles = (max_nq + tq - 1) / tq;
   s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
   const u64 waves = std::max<u64>(1, n_jobs * tiles);
-  u32 splits = 1;
-  if (waves < TARGET_WAVES) splits = (u32)((TARGET_WAVES + waves - 1) / waves);
-  splits = std::min(splits, std::max(1u, max_nt / 32));  // at least 32 train items per split
-  s.splits = std::min(std::max(splits, 1u), 256u);
+  // (a) latency regime: reach TARGET_WAVES with at least 32 train items per split;
+  // (b) long scans (1M x 1M): many short waves balance better than few long ones
+  //     (profiles/r01/nn2_sweep.txt: 1 -> 24 splits = 0.80 -> 0.95 of the roofline).
+  u32 sa = 1, sb = 1;
+  if (waves < TARGET_WAVES) sa = std::min((u32)((TARGET_WAVES + waves - 1) / waves), std::max(1u, max_nt / 32));
+  if (waves < LONG_SCAN_WAVES) sb = std::min((u32)((LONG_SCAN_WAVES + waves - 1) / waves), std::max(1u, max_nt / 4096));
+  s.splits = std::min(std::max(std::max(sa, sb), 1u), 255u);
+  if (vs) s.splits = (u32)vs;
   return s;
 }
 
