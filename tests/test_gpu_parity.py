@@ -107,6 +107,35 @@ def test_batched_uniform_database_vs_oracle(m):
     assert total == len(out) and total > 1000  # the planted overlap is really there
 
 
+def test_pruned_backward_pass_equals_full(m):
+    """The backward scan restricted to nominated columns (nominate_kernel) gives the
+    same lists as scanning every column; dense overlap, no overlap and ragged sizes."""
+    for (n_img, sizes, share, win) in [(12, 900, 0.9, 12), (12, 900, 0.0, 1), (9, [0, 5, 64, 65, 1000, 1, 257, 2000, 333], 0.6, 9)]:
+        db, off = cases.synth.sfm_database(n_img, sizes, seed=91, share_frac=share, window=win)
+        pairs = cases.synth.all_pairs(n_img)
+        pairs = np.concatenate([pairs, pairs[:, ::-1]])
+        m.db_upload(db, off)
+        m.set_variant(0)
+        o1, l1 = m.match_pairs(pairs, 70, 1.2)
+        ev_pruned = m.last_scan_stats()["comparisons"]
+        m.set_variant(0x10000)
+        try:
+            o2, l2 = m.match_pairs(pairs, 70, 1.2)
+            ev_full = m.last_scan_stats()["comparisons"]
+        finally:
+            m.set_variant(0)
+        assert np.array_equal(o1, o2) and np.array_equal(l1, l2)
+        sz = np.diff(off.astype(np.int64))
+        assert ev_full == int((2 * sz[pairs[:, 0]] * sz[pairs[:, 1]]).sum())
+        assert ev_full // 2 <= ev_pruned <= ev_full
+        if share == 0.0:
+            assert len(l1) == 0 or ev_pruned < 0.6 * ev_full
+        k = 7
+        i, j = pairs[k]
+        want = binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(l1[int(o1[k]):int(o1[k + 1])], want)
+
+
 def test_capacity_and_errors(m):
     d1, d2, thr, ratio = cases.build_case("planted_300x777")
     L = vsm.matcher.lib()

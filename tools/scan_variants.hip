@@ -24,7 +24,7 @@ __global__ void checksum(const uint2* s, size_t n, u64* out) {
   atomicAdd((unsigned long long*)out, (unsigned long long)s[i].x * 3 + s[i].y);
 }
 
-typedef void (*scan_fn)(const u32x4*, const u32x4*, const Job*, u32, u32, u32, uint2*);
+typedef void (*scan_fn)(const u32x4*, const u32x4*, const Job*, u32, u32, u32, uint2*, const u32*);
 struct Variant { const char* name; scan_fn fn; int R; };
 
 int main(int argc, char** argv) {
@@ -37,8 +37,8 @@ int main(int argc, char** argv) {
   std::vector<Job> jobs(2 * P);
   for (u32 p = 0; p < P; p++) {
     u32 i = (p * 7 + 1) % n_img, j = (p * 13 + 5) % n_img;
-    jobs[2 * p] = {i * N, N, j * N, N, p * 2 * stride, 0, 0, 0};
-    jobs[2 * p + 1] = {j * N, N, i * N, N, p * 2 * stride + stride, 0, 0, 0};
+    jobs[2 * p] = {i * N, N, j * N, N, p * 2 * stride, NO_QLIST, 0, 0};
+    jobs[2 * p + 1] = {j * N, N, i * N, N, p * 2 * stride + stride, NO_QLIST, 0, 0};
   }
   Job* d_jobs;
   CK(hipMalloc(&d_jobs, jobs.size() * sizeof(Job)));
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
       const u32 tq = 64 * vs[v].R, tiles = (N + tq - 1) / tq, wgs = (tiles + 3) / 4;
       CK(hipMemset(scratch, 0xff, n_scr * sizeof(uint2)));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(vs[v].fn, dim3(2 * P * wgs), dim3(256), 0, 0, (const u32x4*)db, (const u32x4*)db, d_jobs, wgs, 1u, (u32)n_scr, scratch);
+      hipLaunchKernelGGL(vs[v].fn, dim3(2 * P * wgs), dim3(256), 0, 0, (const u32x4*)db, (const u32x4*)db, d_jobs, wgs, 1u, (u32)n_scr, scratch, (const u32*)nullptr);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());

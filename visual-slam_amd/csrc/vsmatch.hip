@@ -116,7 +116,7 @@ struct vsm_ctx {
   std::vector<u32> img_off;
   u32 max_n = 0;
   // work buffers
-  DevBuf stage, scratch, jobs, counts, misc, w_pairs, w_offsets, w_out;
+  DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
   PinBuf pin;
   // measurement
   bool profiling = false;
@@ -217,7 +217,8 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
 }
 
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
-                const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps) {
+                const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
+                const u32* d_qlist = nullptr) {
   if (n_jobs == 0) return VSM_OK;
   const u64 blocks = n_jobs * sh.wgs_per_job;
   if (blocks > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks);
@@ -230,9 +231,9 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   const u32x4* q = (const u32x4*)qbase;
   const u32x4* t = (const u32x4*)tbase;
   switch (sh.R) {
-    case 1: hipLaunchKernelGGL((scan_kernel<1, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
-    case 4: hipLaunchKernelGGL((scan_kernel<4, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
-    case 8: hipLaunchKernelGGL((scan_kernel<8, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch); break;
+    case 1: hipLaunchKernelGGL((scan_kernel<1, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch, d_qlist); break;
+    case 4: hipLaunchKernelGGL((scan_kernel<4, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch, d_qlist); break;
+    case 8: hipLaunchKernelGGL((scan_kernel<8, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch, d_qlist); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
   }
   HIP_TRY(hipGetLastError());
@@ -274,6 +275,13 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   VSM_TRY(c->scratch.reserve(split_stride * sh.splits * sizeof(uint2)));
   VSM_TRY(c->jobs.reserve(chunk * 2 * sizeof(Job)));
   VSM_TRY(c->counts.reserve(chunk * sizeof(u32)));
+  // Pruned backward pass (nominate_kernel): only for unsplit scans and images that
+  // fit the LDS bitmap; bit 16 of the experiment knob turns it off for A/B runs.
+  const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & 0x10000);
+  if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
+  ScanShape shb = sh;  // backward jobs of the pruned pass: one query per lane, ragged lists
+  shb.R = 1;
+  shb.wgs_per_job = std::max(1u, ((max_n + 63) / 64 + 3) / 4);
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
   u32* d_counts = (u32*)c->counts.p;
@@ -281,9 +289,19 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   for (u64 first = 0; first < n_pairs; first += chunk) {
     const u32 n = (u32)std::min<u64>(chunk, n_pairs - first);
     hipLaunchKernelGGL(plan_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream,
-                       d_pairs + first, n, d_img_off, n_img, stride, d_jobs, d_bad, d_comps);
+                       d_pairs + first, n, d_img_off, n_img, stride, d_jobs, d_bad, d_comps,
+                       prune ? 1u : 2u);
     HIP_TRY(hipGetLastError());
-    VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0));
+    if (prune) {
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0));
+      hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
+                         stride, (u32*)c->qlist.p, d_comps);
+      HIP_TRY(hipGetLastError());
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
+                          (const u32*)c->qlist.p));
+    } else {
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0));
+    }
     hipLaunchKernelGGL(count_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
                        sh.splits, (u32)split_stride, prm, d_counts);
     HIP_TRY(hipGetLastError());
@@ -375,7 +393,7 @@ void vsm_destroy(vsm_ctx* c) {
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc,
+    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist,
                       &c->w_pairs, &c->w_offsets, &c->w_out})
       b->release();
     c->pin.release();
@@ -496,8 +514,8 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   memcpy(h, d1, n1 * DESC_BYTES);
   memcpy(h + n1 * DESC_BYTES, d2, n2 * DESC_BYTES);
   const u32 stride = std::max(64u, round_up((u32)std::max(n1, n2), 64));
-  Job jf = {0, (u32)n1, (u32)n1, (u32)n2, 0, 0, 0, 0};
-  Job jb = {(u32)n1, (u32)n2, 0, (u32)n1, stride, 0, 0, 0};
+  Job jf = {0, (u32)n1, (u32)n1, (u32)n2, 0, NO_QLIST, 0, 0};
+  Job jb = {(u32)n1, (u32)n2, 0, (u32)n1, stride, NO_QLIST, 0, 0};
   memcpy(h + (n1 + n2) * DESC_BYTES, &jf, sizeof jf);
   memcpy(h + (n1 + n2) * DESC_BYTES + sizeof jf, &jb, sizeof jb);
   HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
@@ -551,7 +569,7 @@ int vsm_nn2_device(vsm_ctx* c, const void* d_query, size_t nq, const void* d_tra
   VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
   VSM_TRY(c->jobs.reserve(sizeof(Job)));
   VSM_TRY(c->pin.reserve(sizeof(Job)));
-  Job j = {0, (u32)nq, 0, (u32)nt, 0, 0, 0, 0};
+  Job j = {0, (u32)nq, 0, (u32)nt, 0, NO_QLIST, 0, 0};
   memcpy(c->pin.p, &j, sizeof j);
   HIP_TRY(hipMemcpyAsync(c->jobs.p, c->pin.p, sizeof j, hipMemcpyHostToDevice, c->stream));
   VSM_TRY(launch_scan(c, d_query, nt ? d_train : d_query, (const Job*)c->jobs.p, 1, sh, split_stride,

@@ -35,8 +35,11 @@ constexpr u32 KEY_INIT = 256u << IDX_BITS;
 // One scan job: queries [q_off, q_off+nq) of qbase against train [t_off, t_off+nt)
 // of tbase; results go to scratch[out_off + query].  32 bytes so that a wave
 // fetches it with one s_load_dwordx8.
+// qlist_off != NO_QLIST: the job's k-th query is descriptor q_off + qlist[qlist_off + k]
+// and its result goes to scratch[out_off + qlist[qlist_off + k]] (pruned backward pass).
+constexpr u32 NO_QLIST = 0xffffffffu;
 struct __attribute__((aligned(32))) Job {
-  u32 q_off, nq, t_off, nt, out_off, pad0, pad1, pad2;
+  u32 q_off, nq, t_off, nt, out_off, qlist_off, pad1, pad2;
 };
 
 // Host-evaluated accept test.  min_second[b] = smallest s in [0, 256] with
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
                                                    const u32x4* __restrict__ tbase,
                                                    const Job* __restrict__ jobs, u32 wgs_per_job,
                                                    u32 splits, u32 split_stride,
-                                                   uint2* __restrict__ scratch) {
+                                                   uint2* __restrict__ scratch,
+                                                   const u32* __restrict__ qlist) {
   constexpr u32 TQ = 64 * R;
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
@@ -140,11 +144,12 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
   const u32 per = (job.nt + splits - 1) / splits;
   const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
 
-  u32 q[R][8];
+  u32 q[R][8], col[R];
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const u32 qi = min(q0 + r * 64 + lane, job.nq - 1);
-    const u32x4* p = qbase + 2 * (size_t)(job.q_off + qi);
+    col[r] = job.qlist_off != NO_QLIST ? qlist[job.qlist_off + qi] : qi;
+    const u32x4* p = qbase + 2 * (size_t)(job.q_off + col[r]);
     const u32x4 a = p[0], b = p[1];
     q[r][0] = a.x; q[r][1] = a.y; q[r][2] = a.z; q[r][3] = a.w;
     q[r][4] = b.x; q[r][5] = b.y; q[r][6] = b.z; q[r][7] = b.w;
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const u32 qi = q0 + r * 64 + lane;
-    if (qi < job.nq) out[qi] = make_uint2(best[r], second[r]);
+    if (qi < job.nq) out[col[r]] = make_uint2(best[r], second[r]);
   }
 }
 
@@ -203,7 +208,7 @@ __device__ __forceinline__ bool accepted(uint2 v, const uint16_t* lut, int thres
   return d < 256u && (int)d < threshold && s >= (u32)lut[d];
 }
 
-// Pair p of the chunk = jobs[2p] (forward: set 1 queries) and jobs[2p+1]
+// Pair p of an n-pair chunk = jobs[p] (forward: set 1 queries) and jobs[n + p]
 // (backward).  Thread i decides whether (i, best1[i]) survives the cross-check.
 __device__ __forceinline__ bool cross_check(const uint2* __restrict__ scratch, const Job& f,
                                             const Job& b, u32 i, u32 splits, u32 split_stride,
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void count_kernel(const Job* __restrict__ jobs
   __shared__ u32 total;
   if (threadIdx.x == 0) total = 0;
   load_lut(lut, prm);
-  const Job f = jobs[2 * blockIdx.x], b = jobs[2 * blockIdx.x + 1];
+  const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
   u32 mine = 0;
   for (u32 i = threadIdx.x; i < f.nq; i += blockDim.x) {
     u32 j;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256) void fill_kernel(const Job* __restrict__ jobs,
   __shared__ uint16_t lut[260];
   __shared__ u32 wave_cnt[4];
   load_lut(lut, prm);
-  const Job f = jobs[2 * blockIdx.x], b = jobs[2 * blockIdx.x + 1];
+  const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
   const u64 o0 = offsets[first + blockIdx.x];
   if (offsets[first + blockIdx.x + 1] == o0) return;  // uniform: nothing to write
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -315,28 +320,82 @@ __global__ __launch_bounds__(256) void fill_kernel(const Job* __restrict__ jobs,
   }
 }
 
-// jobs[2p], jobs[2p+1] for pair p = (pairs[p].x, pairs[p].y) of the database.
+// jobs[p], jobs[n_pairs + p] for pair p = (pairs[p].x, pairs[p].y) of the database.
 // A pair naming an image >= n_img raises *bad and becomes an empty job pair.
 __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
                                   const u32* __restrict__ img_off, u32 n_img, u32 stride,
                                   Job* __restrict__ jobs, u32* __restrict__ bad,
-                                  u64* __restrict__ comps) {
+                                  u64* __restrict__ comps, u32 dirs) {
   const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   const uint2 pr = pairs[p];
-  Job f = {0, 0, 0, 0, p * 2 * stride, 0, 0, 0}, b = {0, 0, 0, 0, p * 2 * stride + stride, 0, 0, 0};
+  Job f = {0, 0, 0, 0, p * 2 * stride, NO_QLIST, 0, 0}, b = {0, 0, 0, 0, p * 2 * stride + stride, NO_QLIST, 0, 0};
   if (pr.x < n_img && pr.y < n_img) {
     const u32 o1 = img_off[pr.x], n1 = img_off[pr.x + 1] - o1;
     const u32 o2 = img_off[pr.y], n2 = img_off[pr.y + 1] - o2;
     f.q_off = o1; f.nq = n1; f.t_off = o2; f.nt = n2;
     b.q_off = o2; b.nq = n2; b.t_off = o1; b.nt = n1;
-    // comparisons the two scan jobs evaluate (both directions, keypoints.h:256-352)
-    if (n1 && n2) atomicAdd((unsigned long long*)comps, 2ull * n1 * n2);
+    // comparisons the scan jobs evaluate: both directions (keypoints.h:256-352), or
+    // the forward one only when the backward pass is pruned (nominate_kernel adds its own)
+    if (n1 && n2) atomicAdd((unsigned long long*)comps, (unsigned long long)dirs * n1 * n2);
   } else {
     atomicOr(bad, 1u);
   }
-  jobs[2 * p] = f;
-  jobs[2 * p + 1] = b;
+  jobs[p] = f;
+  jobs[n_pairs + p] = b;
+}
+
+// Pruned backward pass.  The cross-check (keypoints.h:354-360) only ever looks at
+// backward results of columns j = best1[i] of forward-ACCEPTED rows i, so only
+// those columns need a backward scan.  Per pair (one 256-thread workgroup): mark
+// the nominated columns in an LDS bitmap, compact them ascending into
+// qlist[p*stride ...] and rewrite the backward job to scan just that list.
+// Exact: every backward result the consumer kernels read is computed.
+// Needs stride <= NOMINATE_MAX_STRIDE (LDS bitmap) and splits == 1.
+constexpr u32 NOMINATE_MAX_STRIDE = 65536;
+__global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
+                                                       const uint2* __restrict__ scratch,
+                                                       AcceptParams prm, u32 stride,
+                                                       u32* __restrict__ qlist,
+                                                       u64* __restrict__ comps) {
+  __shared__ uint16_t lut[260];
+  __shared__ u32 bitmap[NOMINATE_MAX_STRIDE / 32];
+  __shared__ u32 wave_cnt[4];
+  load_lut(lut, prm);
+  const u32 p = blockIdx.x;
+  const Job f = jobs[p];
+  Job b = jobs[gridDim.x + p];
+  const u32 n2 = b.nq, words = (n2 + 31) / 32;
+  for (u32 w = threadIdx.x; w < words; w += 256) bitmap[w] = 0;
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < f.nq; i += 256) {
+    u32 j;
+    if (accepted(scratch[f.out_off + i], lut, prm.threshold, j)) atomicOr(&bitmap[j >> 5], 1u << (j & 31));
+  }
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 done = 0;
+  for (u32 base = 0; base < n2; base += 256) {
+    const u32 j = base + threadIdx.x;
+    const bool hit = j < n2 && ((bitmap[j >> 5] >> (j & 31)) & 1u);
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = done, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
+    }
+    if (hit) qlist[(size_t)p * stride + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = j;
+    done += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    b.nq = done;
+    b.qlist_off = p * stride;
+    jobs[gridDim.x + p] = b;
+    if (done && b.nt) atomicAdd((unsigned long long*)comps, (unsigned long long)done * b.nt);
+  }
 }
 
 // Unpacks scan results (keypoints.h:259-262 conventions: idx -1 / 256 / 256
