@@ -126,6 +126,11 @@ int vsm_match_pairs_device(vsm_ctx* ctx, const void* d_pairs, size_t n_pairs, in
  * how many launches that was and how many 256-bit comparisons they evaluated.
  */
 int vsm_last_scan_stats(vsm_ctx* ctx, double* ms, uint64_t* launches, uint64_t* comparisons);
+/* The same split by launch kind: 0 = full scans and the forward scans of the
+ * batched path, 1 = its pruned backward scans (only the columns a forward-accepted
+ * row points at are scanned backward; the cross-check reads nothing else). */
+int vsm_last_scan_stats_kind(vsm_ctx* ctx, int kind, double* ms, uint64_t* launches,
+                             uint64_t* comparisons);
 /* Enable/disable the event timing above (off by default; costs two events per launch). */
 int vsm_set_profiling(vsm_ctx* ctx, int enabled);
 /* Kernel variant selector for experiments: 0 = default. See DESIGN.md. */

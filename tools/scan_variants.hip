@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
       const u32 tq = 64 * vs[v].R, tiles = (N + tq - 1) / tq, wgs = (tiles + 3) / 4;
       CK(hipMemset(scratch, 0xff, n_scr * sizeof(uint2)));
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(vs[v].fn, dim3(2 * P * wgs), dim3(256), 0, 0, (const u32x4*)db, (const u32x4*)db, d_jobs, wgs, 1u, (u32)n_scr, scratch, (const u32*)nullptr);
+      hipLaunchKernelGGL(vs[v].fn, dim3(2 * P * wgs), dim3(256), 0, 0, (const u32x4*)db, (const u32x4*)db, d_jobs, 2 * P, 1u, (u32)n_scr, scratch, (const u32*)nullptr);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());

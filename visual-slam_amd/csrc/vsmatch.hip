@@ -122,8 +122,10 @@ struct vsm_ctx {
   bool profiling = false;
   std::vector<hipEvent_t> ev;
   size_t ev_used = 0;
-  double scan_ms = 0;
-  u64 scan_launches = 0, scan_comps = 0;
+  // per kind: 0 = full / forward scans, 1 = pruned backward scans
+  double scan_ms[2] = {0, 0};
+  u64 scan_launches[2] = {0, 0}, scan_comps[2] = {0, 0};
+  std::vector<int> ev_kind;
   int variant = 0;
 };
 
@@ -170,9 +172,12 @@ int ev_pair(vsm_ctx* c, hipEvent_t* a, hipEvent_t* b) {
 
 void stats_reset(vsm_ctx* c) {
   c->ev_used = 0;
-  c->scan_ms = 0;
-  c->scan_launches = 0;
-  c->scan_comps = 0;
+  c->ev_kind.clear();
+  for (int k = 0; k < 2; k++) {
+    c->scan_ms[k] = 0;
+    c->scan_launches[k] = 0;
+    c->scan_comps[k] = 0;
+  }
 }
 
 // After the stream has been synchronised: sum the event pairs.
@@ -180,9 +185,10 @@ int stats_collect(vsm_ctx* c) {
   for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-    c->scan_ms += ms;
+    c->scan_ms[c->ev_kind[i / 2]] += ms;
   }
   c->ev_used = 0;
+  c->ev_kind.clear();
   return VSM_OK;
 }
 
@@ -219,6 +225,7 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
                 const u32* d_qlist = nullptr) {
+  const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
   const u64 blocks = n_jobs * sh.wgs_per_job;
   if (blocks > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks);
@@ -226,20 +233,22 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profiling) {
     VSM_TRY(ev_pair(c, &e0, &e1));
+    c->ev_kind.push_back(kind);
     HIP_TRY(hipEventRecord(e0, c->stream));
   }
   const u32x4* q = (const u32x4*)qbase;
   const u32x4* t = (const u32x4*)tbase;
   switch (sh.R) {
-    case 1: hipLaunchKernelGGL((scan_kernel<1, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch, d_qlist); break;
-    case 4: hipLaunchKernelGGL((scan_kernel<4, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch, d_qlist); break;
-    case 8: hipLaunchKernelGGL((scan_kernel<8, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, sh.wgs_per_job, sh.splits, split_stride, d_scratch, d_qlist); break;
+    case 1: hipLaunchKernelGGL((scan_kernel<1, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
+    case 2: hipLaunchKernelGGL((scan_kernel<2, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
+    case 4: hipLaunchKernelGGL((scan_kernel<4, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
+    case 8: hipLaunchKernelGGL((scan_kernel<8, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
   }
   HIP_TRY(hipGetLastError());
   if (c->profiling) HIP_TRY(hipEventRecord(e1, c->stream));
-  c->scan_launches++;
-  c->scan_comps += comps;
+  c->scan_launches[kind]++;
+  c->scan_comps[kind] += comps;
   return VSM_OK;
 }
 
@@ -251,11 +260,12 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        const uint2* d_pairs, size_t n_pairs,
                        const AcceptParams& prm, u64* d_out_offsets, int2* d_out_pairs,
                        size_t cap_pairs, size_t* out_total) {
-  // `misc`: [u64 running total][u64 comparisons evaluated][u32 bad-pair flag]
+  // `misc`: [u64 running total][u64 comparisons, full/forward scans][u64 comparisons,
+  //          pruned backward scans][u32 bad-pair flag]
   VSM_TRY(c->misc.reserve(64));
   u64* d_running = (u64*)c->misc.p;
   u64* d_comps = d_running + 1;
-  u32* d_bad = (u32*)(d_running + 2);
+  u32* d_bad = (u32*)(d_running + 3);
   HIP_TRY(hipMemsetAsync(c->misc.p, 0, 32, c->stream));
   if (n_pairs == 0) {
     HIP_TRY(hipMemsetAsync(d_out_offsets, 0, sizeof(u64), c->stream));
@@ -281,7 +291,9 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
   ScanShape shb = sh;  // backward jobs of the pruned pass: one query per lane, ragged lists
   shb.R = 1;
-  shb.wgs_per_job = std::max(1u, ((max_n + 63) / 64 + 3) / 4);
+  const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
+  if (vbr == 1 || vbr == 2 || vbr == 4 || vbr == 8) shb.R = vbr;
+  shb.wgs_per_job = std::max(1u, ((max_n + 64 * shb.R - 1) / (64 * shb.R) + 3) / 4);
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
   u32* d_counts = (u32*)c->counts.p;
@@ -295,7 +307,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     if (prune) {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, d_comps);
+                         stride, (u32*)c->qlist.p, d_comps + 1);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p));
@@ -313,14 +325,15 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     HIP_TRY(hipGetLastError());
   }
   struct {
-    u64 total, comps;
+    u64 total, comps_fwd, comps_bwd;
     u32 bad;
     u32 pad;
   } h;
-  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 24, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->profiling) VSM_TRY(stats_collect(c));
-  c->scan_comps = h.comps;
+  c->scan_comps[0] = h.comps_fwd;
+  c->scan_comps[1] = h.comps_bwd;
   *out_total = (size_t)h.total;
   if (h.bad) return fail(VSM_ERR_INVALID, "a pair names an image index >= %u", n_img);
   if (h.total > cap_pairs)
@@ -421,9 +434,19 @@ int vsm_set_variant(vsm_ctx* c, int variant) {
 int vsm_last_scan_stats(vsm_ctx* c, double* ms, uint64_t* launches, uint64_t* comparisons) {
   VSM_TRY(check_ctx(c));
   std::lock_guard<std::recursive_mutex> lk(c->mu);
-  if (ms) *ms = c->scan_ms;
-  if (launches) *launches = c->scan_launches;
-  if (comparisons) *comparisons = c->scan_comps;
+  if (ms) *ms = c->scan_ms[0] + c->scan_ms[1];
+  if (launches) *launches = c->scan_launches[0] + c->scan_launches[1];
+  if (comparisons) *comparisons = c->scan_comps[0] + c->scan_comps[1];
+  return VSM_OK;
+}
+
+int vsm_last_scan_stats_kind(vsm_ctx* c, int kind, double* ms, uint64_t* launches, uint64_t* comparisons) {
+  VSM_TRY(check_ctx(c));
+  if (kind < 0 || kind > 1) return fail(VSM_ERR_INVALID, "kind must be 0 (full/forward) or 1 (pruned backward)");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (ms) *ms = c->scan_ms[kind];
+  if (launches) *launches = c->scan_launches[kind];
+  if (comparisons) *comparisons = c->scan_comps[kind];
   return VSM_OK;
 }
 

@@ -120,7 +120,11 @@ __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 
 // wave-uniform loads become s_load_dwordx8 (scalar data cache, read only).
 typedef const __attribute__((address_space(4))) u32x8 cdesc_t;
 
-// Grid: x = job * wgs_per_job + workgroup-of-job, y = train split.  A wave is
+// Grid: x = workgroup-of-job * n_jobs + job (job-minor, so that the workgroups the
+// dispatcher deals round-robin to the 8 XCDs mix full and empty tiles of ragged
+// jobs evenly: with job-major order and 8 workgroups per job, whole XCDs got
+// nothing but empty tiles and the pruned backward pass ran at half speed),
+// y = train split.  A wave is
 // the unit of work: it owns 64*R consecutive queries of one job (lane l holds
 // queries q0 + r*64 + l, so every query load is a coalesced 2 KiB) and scans
 // its split of the train range.  Waves never communicate; there is no LDS and
@@ -128,15 +132,16 @@ typedef const __attribute__((address_space(4))) u32x8 cdesc_t;
 template <int R, int FILL = 0>
 __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qbase,
                                                    const u32x4* __restrict__ tbase,
-                                                   const Job* __restrict__ jobs, u32 wgs_per_job,
+                                                   const Job* __restrict__ jobs, u32 n_jobs,
                                                    u32 splits, u32 split_stride,
                                                    uint2* __restrict__ scratch,
                                                    const u32* __restrict__ qlist) {
   constexpr u32 TQ = 64 * R;
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  const u32 job_id = blockIdx.x / wgs_per_job;
-  const u32 tile = (blockIdx.x - job_id * wgs_per_job) * 4 + wave;
+  const u32 wg_of_job = blockIdx.x / n_jobs;
+  const u32 job_id = blockIdx.x - wg_of_job * n_jobs;
+  const u32 tile = wg_of_job * 4 + wave;
   const u32 split = blockIdx.y;
   const Job job = jobs[job_id];
   const u32 q0 = tile * TQ;

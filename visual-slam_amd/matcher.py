@@ -25,7 +25,8 @@ VSM_MAX_SET = 1 << 23
 SYMBOLS = (
     "vsm_version", "vsm_last_error", "vsm_create", "vsm_destroy", "vsm_stream",
     "vsm_match_pair", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
-    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_set_profiling",
+    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
+    "vsm_set_profiling",
     "vsm_set_variant",
 )
 
@@ -65,6 +66,7 @@ def lib():
             L.vsm_match_pairs.argtypes = [_vp, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz, C.POINTER(_sz)]
             L.vsm_match_pairs_device.argtypes = [_vp, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz, C.POINTER(_sz)]
             L.vsm_last_scan_stats.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            L.vsm_last_scan_stats_kind.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
             _lib = L
@@ -197,9 +199,13 @@ class Matcher:
     def set_variant(self, v: int):
         _check(lib().vsm_set_variant(self._h, int(v)))
 
-    def last_scan_stats(self):
+    def last_scan_stats(self, kind: int | None = None):
+        """kind None = all scan launches of the last call, 0 = full/forward, 1 = pruned backward."""
         ms, n, comps = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
-        _check(lib().vsm_last_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(comps)))
+        if kind is None:
+            _check(lib().vsm_last_scan_stats(self._h, C.byref(ms), C.byref(n), C.byref(comps)))
+        else:
+            _check(lib().vsm_last_scan_stats_kind(self._h, int(kind), C.byref(ms), C.byref(n), C.byref(comps)))
         return {"scan_ms": ms.value, "launches": n.value, "comparisons": comps.value}
 
 
