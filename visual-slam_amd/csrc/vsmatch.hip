@@ -215,7 +215,7 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
   // (b) long scans (1M x 1M): many short waves balance better than few long ones
   //     (profiles/r01/nn2_sweep.txt: 1 -> 24 splits = 0.80 -> 0.95 of the roofline).
   u32 sa = 1, sb = 1;
-  if (waves < TARGET_WAVES) sa = std::min((u32)((TARGET_WAVES + waves - 1) / waves), std::max(1u, max_nt / 32));
+  if (waves < TARGET_WAVES) sa = std::min((u32)((TARGET_WAVES + waves - 1) / waves), std::max(1u, max_nt / 64));
   if (waves < LONG_SCAN_WAVES) sb = std::min((u32)((LONG_SCAN_WAVES + waves - 1) / waves), std::max(1u, max_nt / 4096));
   s.splits = std::min(std::max(std::max(sa, sb), 1u), 255u);
   if (vs) s.splits = (u32)vs;
@@ -314,13 +314,19 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     } else {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0));
     }
+    if (sh.splits > 1) {
+      const u32 n_entries = n * 2 * stride;
+      hipLaunchKernelGGL(merge_splits_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, c->stream,
+                         d_scratch, n_entries, sh.splits, (u32)split_stride);
+      HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(count_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
-                       sh.splits, (u32)split_stride, prm, d_counts);
+                       1u, (u32)split_stride, prm, d_counts);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, d_counts, n,
                        d_out_offsets, first, d_running);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, sh.splits,
+    hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, 1u,
                        (u32)split_stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);
     HIP_TRY(hipGetLastError());
   }
@@ -555,12 +561,15 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
                       2ull * n1 * n2));
   u64* d_off = (u64*)c->w_out.p;
   int2* d_out = (int2*)((char*)c->w_out.p + 16);
+  if (sh.splits > 1)
+    hipLaunchKernelGGL(merge_splits_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream,
+                       (uint2*)c->scratch.p, split_stride, sh.splits, split_stride);
   hipLaunchKernelGGL(count_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
-                     sh.splits, split_stride, prm, (u32*)c->counts.p);
+                     1u, split_stride, prm, (u32*)c->counts.p);
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->counts.p, 1u,
                      d_off, (u64)0, d_running);
   hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
-                     sh.splits, split_stride, prm, (const u64*)d_off, (u64)0, d_out, (u64)nmin);
+                     1u, split_stride, prm, (const u64*)d_off, (u64)0, d_out, (u64)nmin);
   HIP_TRY(hipGetLastError());
   char* hd = h + up_bytes;
   HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -204,6 +204,20 @@ __device__ __forceinline__ uint2 load_merged(const uint2* __restrict__ scratch, 
   return v;
 }
 
+// Folds the partial results of train splits 1..splits-1 into split 0, in place, one
+// thread per scratch entry (entries no scan wrote are garbage in, garbage out and
+// never read).  After it the consumer kernels run with splits = 1; without it a
+// single pair split 46 ways spent 175 us in count/fill's serial merge loops.
+__global__ __launch_bounds__(256) void merge_splits_kernel(uint2* __restrict__ scratch, u32 n,
+                                                           u32 splits, u32 split_stride) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint2 v = scratch[i];
+#pragma unroll 8
+  for (u32 s = 1; s < splits; s++) v = merge2(v, scratch[(size_t)s * split_stride + i]);
+  scratch[i] = v;
+}
+
 // keypoints.h:295-296: int(best) < threshold && dist_2_best*best <= second, plus
 // "best_match == -1 can never be emitted" (distance 256).
 __device__ __forceinline__ bool accepted(uint2 v, const uint16_t* lut, int threshold, u32& idx) {
