@@ -255,6 +255,13 @@ def main():
         "evaluated_over_reference_equivalent": scan_comps / comps_rank,
         "hbm_algorithmic_bytes_per_pair": int(32 * 2 * a.desc),
     }
+    try:  # HBM bytes per launch of the dominant kernel, from the committed PMC passes
+        with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as f:
+            tr = json.load(f)
+        roofline["traffic"] = tr["bytes_per_pair"] * P
+        roofline["traffic_source"] = "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per pair x pairs per launch)"
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "hamming_comparisons_per_sec", "value": comps_all / dt / 1e9, "unit": "Gcomp/s",
         "n_gpus": world, "rehearsal_on_one_gpu": bool(a.rehearse), "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

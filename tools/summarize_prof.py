@@ -31,3 +31,20 @@ with open(os.path.join(dst, "pmc_counters.txt"), "w") as f:
             f.write(f"{name.split('(')[0]:50s} {ctr:22s} {n:4d} {avg:20.1f}\n")
 print(open(os.path.join(dst, "kernel_trace_stats.txt")).read())
 print(open(os.path.join(dst, "pmc_counters.txt")).read())
+
+# HBM traffic of the dominant kernel per image pair, for bench.py's roofline.traffic
+import json
+vals = {}
+for d, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    p = os.path.join(src, d, "p_results.db")
+    r = q(p, "select avg(value) from counters_collection where counter_name='%s' and kernel_name like '%%scan_kernel<4%%'" % ctr)
+    vals[ctr] = r[0][0]
+pairs = 16384
+json.dump({"kernel": "scan_kernel<4,2>", "pairs_per_launch": pairs,
+           "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
+           "bytes_per_pair": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / pairs,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh); raw counter "
+                   "values in KiB. FETCH_SIZE is NOT doubled: the x2 gfx950 correction of MI355X_MICROARCH.md is "
+                   "calibrated for 16 B/lane streaming reads; this kernel reads through s_load_dwordx8 and "
+                   "global_load_dwordx4, uncalibrated. WRITE_SIZE equals the algorithmic 8 B per query exactly."},
+          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
