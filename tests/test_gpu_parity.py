@@ -47,9 +47,10 @@ def test_pair_matches_recorded_reference(m, name):
     assert np.array_equal(got, binding.port().match(d1, d2, thr, ratio))
 
 
-@pytest.mark.parametrize("variant", [1, 4, 8])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008])
 def test_pair_all_kernel_shapes(m, variant):
-    """Every queries-per-lane instantiation gives the same list."""
+    """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
+    tracking [bit 17], with forced train splits [bits 8-15]) gives the same list."""
     m.set_variant(variant)
     try:
         for name in ("ex3_thr70_r1.2", "planted_300x777", "planted_1023x1025", "planted_4100x130",
@@ -61,12 +62,18 @@ def test_pair_all_kernel_shapes(m, variant):
 
 
 def test_nn2_vs_oracle(m):
-    for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6)]:
-        q, t = cases.synth.orb_like_pair(nq, nt, seed)
-        got = m.nn2(q, t)
-        want = binding.port().nn2(q, t)
-        for g, w in zip(got, want):
-            assert np.array_equal(g, w), (nq, nt)
+    for variant in (0, 0x20000):
+        m.set_variant(variant)
+        try:
+            for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6),
+                                   (300, 40000, 7), (130, 70001, 8)]:  # the last two exceed one float-key range
+                q, t = cases.synth.orb_like_pair(nq, nt, seed)
+                got = m.nn2(q, t)
+                want = binding.port().nn2(q, t)
+                for g, w in zip(got, want):
+                    assert np.array_equal(g, w), (variant, nq, nt)
+        finally:
+            m.set_variant(0)
     q, _ = cases.synth.orb_like_pair(10, 10, 9)
     bi, bd, sd = m.nn2(q, np.zeros((0, 4), np.uint64))
     assert list(bi) == [-1] * 10 and list(bd) == [256] * 10 and list(sd) == [256] * 10

@@ -52,8 +52,8 @@ int main(int argc, char** argv) {
       {"R4 fill0 (shipped)", scan_kernel<4, 0>, 4}, {"R4 fill1 s_nop", scan_kernel<4, 1>, 4}, {"R4 fill2 v_mov", scan_kernel<4, 2>, 4},
       {"R2 fill2", scan_kernel<2, 2>, 2},
       {"R8 fill0", scan_kernel<8, 0>, 8}, {"R8 fill1", scan_kernel<8, 1>, 8}, {"R8 fill2", scan_kernel<8, 2>, 8},
-      {"R4 fill3 mov all C", scan_kernel<4, 3>, 4}, {"R4 fill4 nop all C", scan_kernel<4, 4>, 4},
-      {"R8 fill3 mov all C", scan_kernel<8, 3>, 8}, {"R8 fill4 nop all C", scan_kernel<8, 4>, 8},
+      {"R4 fill5 f32 key", scan_kernel<4, 5>, 4}, {"R8 fill5 f32 key", scan_kernel<8, 5>, 8},
+      {"R2 fill5 f32 key", scan_kernel<2, 5>, 2}, {"R1 fill5 f32 key", scan_kernel<1, 5>, 1}, {"R1 fill2", scan_kernel<1, 2>, 1},
   };
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -97,8 +97,6 @@ struct PinBuf {
 };
 
 constexpr size_t DESC_BYTES = 32;
-// v_mov filler behind every v_bcnt: +10 % on MI355X (profiles/r01/scan_variants.txt)
-constexpr int SCAN_FILL = 2;
 constexpr size_t SCRATCH_BUDGET = (size_t)2 << 30;  // scan results per chunk of pairs
 constexpr u32 TARGET_WAVES = 4096;                  // below this the train range is split
 constexpr u32 LONG_SCAN_WAVES = 98304;              // 16 x the 6144 resident waves of scan_kernel<4>
@@ -195,6 +193,7 @@ int stats_collect(vsm_ctx* c) {
 struct ScanShape {
   int R;
   u32 wgs_per_job, splits;
+  bool fkey;  // float-key tracking (scan range per split <= FKEY_MAX_SET)
 };
 
 // Queries per wave (64*R) and train splits.  Large batches: R = 4, no split.
@@ -202,23 +201,29 @@ struct ScanShape {
 // query per lane and the train range split over grid.y so that all 256 CUs work.
 ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
   ScanShape s;
-  const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256);
-  s.R = waves_r4 >= TARGET_WAVES ? 4 : 1;
-  // experiment knob (vsm_set_variant): low byte = R override, next byte = splits override
+  // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
+  // override, bit 17 = integer-key tracking everywhere
   const int vr = variant & 0xff, vs = (variant >> 8) & 0xff;
-  if (vr == 1 || vr == 4 || vr == 8) s.R = vr;
+  const u64 waves_r8 = n_jobs * ((max_nq + 511) / 512);
+  const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256);
+  s.R = waves_r8 >= TARGET_WAVES ? 8 : waves_r4 >= TARGET_WAVES ? 4 : 1;
+  if (vr == 1 || vr == 2 || vr == 4 || vr == 8) s.R = vr;
   const u32 tq = 64 * s.R;
   const u32 tiles = (max_nq + tq - 1) / tq;
   s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
   const u64 waves = std::max<u64>(1, n_jobs * tiles);
-  // (a) latency regime: reach TARGET_WAVES with at least 32 train items per split;
+  // (a) latency regime: reach TARGET_WAVES with at least 64 train items per split;
   // (b) long scans (1M x 1M): many short waves balance better than few long ones
-  //     (profiles/r01/nn2_sweep.txt: 1 -> 24 splits = 0.80 -> 0.95 of the roofline).
+  //     (profiles/r01/nn2_sweep.txt: 1 -> 24 splits = 0.80 -> 0.95 of the roofline);
+  // (c) float-key tracking wants <= FKEY_MAX_SET train items per split.
   u32 sa = 1, sb = 1;
   if (waves < TARGET_WAVES) sa = std::min((u32)((TARGET_WAVES + waves - 1) / waves), std::max(1u, max_nt / 64));
   if (waves < LONG_SCAN_WAVES) sb = std::min((u32)((LONG_SCAN_WAVES + waves - 1) / waves), std::max(1u, max_nt / 4096));
-  s.splits = std::min(std::max(std::max(sa, sb), 1u), 255u);
+  const u32 sc = (max_nt + FKEY_MAX_SET - 1) / FKEY_MAX_SET;
+  s.splits = std::min(std::max(std::max(sa, sb), std::max(sc, 1u)), 256u);
   if (vs) s.splits = (u32)vs;
+  const u32 per = (max_nt + s.splits - 1) / s.splits;
+  s.fkey = per <= FKEY_MAX_SET && !(variant & 0x20000);
   return s;
 }
 
@@ -238,13 +243,23 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   }
   const u32x4* q = (const u32x4*)qbase;
   const u32x4* t = (const u32x4*)tbase;
-  switch (sh.R) {
-    case 1: hipLaunchKernelGGL((scan_kernel<1, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
-    case 2: hipLaunchKernelGGL((scan_kernel<2, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
-    case 4: hipLaunchKernelGGL((scan_kernel<4, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
-    case 8: hipLaunchKernelGGL((scan_kernel<8, SCAN_FILL>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, d_qlist); break;
+#define VSM_LAUNCH(RR, FF)                                                                          \
+  hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
+                     sh.splits, split_stride, d_scratch, d_qlist)
+  // FILL 5 = float-key tracking (train range per split <= 32768), FILL 2 = integer keys
+  // with a v_mov filler behind every v_bcnt; both measured in profiles/r01/scan_variants.txt
+  switch (sh.R * 2 + (sh.fkey ? 1 : 0)) {
+    case 2: VSM_LAUNCH(1, 2); break;
+    case 3: VSM_LAUNCH(1, 5); break;
+    case 4: VSM_LAUNCH(2, 2); break;
+    case 5: VSM_LAUNCH(2, 5); break;
+    case 8: VSM_LAUNCH(4, 2); break;
+    case 9: VSM_LAUNCH(4, 5); break;
+    case 16: VSM_LAUNCH(8, 2); break;
+    case 17: VSM_LAUNCH(8, 5); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
   }
+#undef VSM_LAUNCH
   HIP_TRY(hipGetLastError());
   if (c->profiling) HIP_TRY(hipEventRecord(e1, c->stream));
   c->scan_launches[kind]++;
@@ -291,6 +306,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
   ScanShape shb = sh;  // backward jobs of the pruned pass: one query per lane, ragged lists
   shb.R = 1;
+  shb.fkey = sh.fkey;
   const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
   if (vbr == 1 || vbr == 2 || vbr == 4 || vbr == 8) shb.R = vbr;
   shb.wgs_per_job = std::max(1u, ((max_n + 64 * shb.R - 1) / (64 * shb.R) + 3) / 4);

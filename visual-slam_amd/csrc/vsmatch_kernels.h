@@ -84,9 +84,53 @@ __device__ __forceinline__ u32 bcnt0(u32 x) {
 // One train descriptor (wave-uniform, in SGPRs) against the R query descriptors
 // each lane holds in VGPRs: 8 xor + 8 bcnt + key + med3 + min per comparison.
 // Invariant best <= second, so the new second is the median of (best, key, second).
+//
+// FILL == 5: float-key tracking for train sets of <= 32768 descriptors.  The
+// popcount chain is seeded with 0x4B000000, the bit pattern of 2^23, so its
+// result read as f32 is exactly 2^23 + d.  Then
+//     df  = chain - 2^23                       (v_add_f32, exact)
+//     key = df * 32768 + (2^23 + j)            (v_fma_f32, exact: < 2^24 for d <= 255)
+// is an f32 whose order is (distance, index) lexicographic, and best/second are
+// kept with v_med3_f32 / v_min_f32.  The two f32 instructions are of the class
+// that issues in the shadow of a v_bcnt (tools/valu_rate2), so the v_add_f32
+// replaces the filler of the last v_bcnt and the integer v_lshl_or_b32
+// disappears.  Distance 256 gives key >= 2^24 = the start value: never recorded.
+constexpr u32 FKEY_MAGIC = 0x4B000000u;   // 2^23 as f32
+constexpr u32 FKEY_INIT = 0x4B800000u;    // 2^24 as f32 = distance 256, index 0
+constexpr u32 FKEY_MAX_SET = 32768;
+// f32 key -> packed integer key; `base` = first train index of the scanned range
+// (float keys index relative to it so that any range of <= 32768 descriptors works).
+__device__ __forceinline__ u32 fkey_to_key(u32 fbits, u32 base) {
+  const u32 k = (u32)(__uint_as_float(fbits) - 8388608.0f);  // d * 32768 + j, exact
+  const u32 d = k >> 15;
+  return d >= 256u ? KEY_INIT : ((d << IDX_BITS) | ((k & 32767u) + base));
+}
+
 template <int R, int FILL>
 __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 j, u32 (&best)[R],
                                        u32 (&second)[R]) {
+  if (FILL == 5) {
+    const u32 magic = FKEY_MAGIC;
+    const float scale = 32768.0f;
+    const u32 jf = FKEY_MAGIC + j;  // SALU: bit pattern of 2^23 + j
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      u32 d = bcnt_acc<2>(q[r][0] ^ t[0], magic);
+#pragma unroll
+      for (int w = 1; w < 7; w++) d = bcnt_acc<2>(q[r][w] ^ t[w], d);
+      u32 nb, ns, key, df;
+      asm("v_bcnt_u32_b32 %3, %4, %5\n\t"
+          "v_add_f32 %3, 0xcb000000, %3\n\t"
+          "v_fma_f32 %0, %3, %6, %7\n\t"
+          "v_med3_f32 %1, %8, %0, %9\n\t"
+          "v_min_f32 %2, %8, %0"
+          : "=&v"(key), "=&v"(ns), "=&v"(nb), "=&v"(df)
+          : "v"(q[r][7] ^ t[7]), "v"(d), "v"(scale), "s"(jf), "v"(best[r]), "v"(second[r]));
+      second[r] = ns;
+      best[r] = nb;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
     u32 d = bcnt0<FILL>(q[r][0] ^ t[0]);
@@ -161,11 +205,12 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
   }
   u32 best[R], second[R];
 #pragma unroll
-  for (int r = 0; r < R; r++) best[r] = second[r] = KEY_INIT;
+  for (int r = 0; r < R; r++) best[r] = second[r] = (FILL == 5 ? FKEY_INIT : KEY_INIT);
 
   if (t1 > t0) {
     cdesc_t* tr = (cdesc_t*)(uintptr_t)tbase + job.t_off;
     const u32 last = t1 - 1;
+    const u32 jb = FILL == 5 ? t0 : 0u;  // float keys count from the start of the range
     u32 j = t0;
     // Software-pipelined: two groups of two descriptors in SGPRs; the loads of
     // one group are in flight while the other is consumed.  Indices past the
@@ -173,20 +218,24 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
     u32x8 a0 = tr[min(j, last)], a1 = tr[min(j + 1, last)];
     for (; j + 4 <= t1; j += 4) {
       const u32x8 b0 = tr[j + 2], b1 = tr[j + 3];
-      update<R, FILL>(q, a0, j, best, second);
-      update<R, FILL>(q, a1, j + 1, best, second);
+      update<R, FILL>(q, a0, j - jb, best, second);
+      update<R, FILL>(q, a1, j + 1 - jb, best, second);
       a0 = tr[min(j + 4, last)];
       a1 = tr[min(j + 5, last)];
-      update<R, FILL>(q, b0, j + 2, best, second);
-      update<R, FILL>(q, b1, j + 3, best, second);
+      update<R, FILL>(q, b0, j + 2 - jb, best, second);
+      update<R, FILL>(q, b1, j + 3 - jb, best, second);
     }
-    for (; j < t1; ++j) update<R, FILL>(q, tr[j], j, best, second);
+    for (; j < t1; ++j) update<R, FILL>(q, tr[j], j - jb, best, second);
   }
 
   uint2* out = scratch + (size_t)split * split_stride + job.out_off;
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const u32 qi = q0 + r * 64 + lane;
+    if (FILL == 5) {
+      best[r] = fkey_to_key(best[r], t0);
+      second[r] = fkey_to_key(second[r], t0);
+    }
     if (qi < job.nq) out[col[r]] = make_uint2(best[r], second[r]);
   }
 }
