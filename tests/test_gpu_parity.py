@@ -179,3 +179,46 @@ def test_cpp_shim_reference_signature():
     r = subprocess.run([exe, os.path.join(g, "ex3_kd0.npy"), os.path.join(g, "ex3_kd1.npy"),
                         os.path.join(g, "ex3_matches.npy")], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_config3_shape_euroc_like_all_pairs(m):
+    """BASELINE config 3 shape: 164 images (82 stereo frames) of ~1200-1500 descriptors,
+    the 13284 non-stereo pairs of sfm.cpp:1285-1290.  Sampled pairs against the oracle;
+    all pairs through the argument-swap property (size independent)."""
+    rng = np.random.default_rng(3)
+    sizes = rng.integers(1200, 1501, size=164)
+    db, off = cases.synth.sfm_database(164, sizes, seed=55, share_frac=0.5, window=12)
+    frame = np.repeat(np.arange(82), 2)
+    pairs = cases.synth.all_pairs(164, frame)
+    assert len(pairs) == 13284
+    m.db_upload(db, off)
+    o1, l1 = m.match_pairs(pairs, 70, 1.2)
+    o2, l2 = m.match_pairs(pairs[:, ::-1], 70, 1.2)
+    assert int(o1[-1]) == len(l1) == len(l2) and len(l1) > 10000
+    assert np.array_equal(np.diff(o1.astype(np.int64)), np.diff(o2.astype(np.int64)))
+    # transposed sets pair by pair: sort the swapped list of each pair by its second column
+    pid1 = np.repeat(np.arange(len(pairs)), np.diff(o1.astype(np.int64)))
+    pid2 = np.repeat(np.arange(len(pairs)), np.diff(o2.astype(np.int64)))
+    a = np.stack([pid1, l1[:, 0], l1[:, 1]], axis=1)
+    b = np.stack([pid2, l2[:, 1], l2[:, 0]], axis=1)
+    b = b[np.lexsort((b[:, 1], b[:, 0]))]
+    assert np.array_equal(a, b)
+    for k in rng.choice(len(pairs), size=120, replace=False):
+        i, j = pairs[k]
+        want = binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(l1[int(o1[k]):int(o1[k + 1])], want), (k, i, j)
+
+
+def test_nn2_large_sampled_against_oracle(m):
+    """One-direction scan at 200k x 200k (several float-key ranges, R = 8): invariants on
+    every query, exact values on a sample."""
+    n = 200_000
+    q, t = cases.synth.planted_sets(n, seed=8)
+    bi, bd, sd = m.nn2(q, t)
+    assert bi.min() >= 0 and bi.max() < n
+    assert np.all(bd <= sd) and bd.min() >= 0 and sd.max() <= 256
+    assert (bd < 70).sum() > n // 3  # the planted half is found
+    rng = np.random.default_rng(4)
+    pick = rng.choice(n, size=48, replace=False)
+    wi, wd, ws = binding.port().nn2(q[pick], t)
+    assert np.array_equal(bi[pick], wi) and np.array_equal(bd[pick], wd) and np.array_equal(sd[pick], ws)

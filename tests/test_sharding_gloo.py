@@ -48,6 +48,37 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _nn2_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b = cases.synth.orb_like_pair(1001, 777, seed=5)
+        res = sfm_pairs.nn2_sharded(a, b, device="cpu", nn2_fn=binding.port().nn2)
+        if rank == world - 1:
+            q.put([r.tolist() for r in res])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_nn2_equals_single_process(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nn2_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = cases.synth.orb_like_pair(1001, 777, seed=5)
+    want = binding.port().nn2(a, b)
+    for g, w in zip(got, want):
+        assert g == w.tolist()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -15,7 +15,7 @@ m = vsm.Matcher(0)
 m.set_profiling(True)
 ref = None
 for R in (4, 8):
-    for splits in (1, 2, 3, 6, 12, 24):
+    for splits in (32, 48, 64, 128):
         m.set_variant(R | (splits << 8))
         best = 1e9
         for rep in range(2):

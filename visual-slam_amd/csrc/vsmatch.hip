@@ -204,8 +204,11 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
   // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
   // override, bit 17 = integer-key tracking everywhere
   const int vr = variant & 0xff, vs = (variant >> 8) & 0xff;
-  const u64 waves_r8 = n_jobs * ((max_nq + 511) / 512);
-  const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256);
+  // 8 queries per lane when that still leaves enough waves to fill the chip (counting the
+  // long-scan splits that will be applied below), else 4, else 1 (latency regime).
+  const u64 long_splits = std::max(1u, max_nt / 4096);
+  const u64 waves_r8 = n_jobs * ((max_nq + 511) / 512) * long_splits;
+  const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256) * long_splits;
   s.R = waves_r8 >= TARGET_WAVES ? 8 : waves_r4 >= TARGET_WAVES ? 4 : 1;
   if (vr == 1 || vr == 2 || vr == 4 || vr == 8) s.R = vr;
   const u32 tq = 64 * s.R;

@@ -127,3 +127,42 @@ def match_all_sharded(desc, offsets, pairs, threshold: int = 70, dist_2_best: fl
     mine = shard_indices(len(pairs), rank, world, block)
     loc_off, loc_matches = match_pairs_fn(desc, offsets, pairs[mine], threshold, dist_2_best)
     return gather_matches(mine, np.asarray(loc_off), np.asarray(loc_matches), len(pairs), device, group)
+
+
+# ---- 1M x 1M style one-direction matching (BASELINE.json config 4) -------------------------
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous query block of `rank`: [lo, hi)."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+def nn2_sharded(query, train, group=None, device="cpu", nn2_fn=None):
+    """keypoints.h:256-290 for a huge query set: queries are sharded over ranks in
+    contiguous blocks, the train set is replicated (every rank passes the same
+    `train`), no merge is needed; one all-gather returns the full
+    (best_idx, best_dist, second_dist) int32[nq] on every rank (the cross-check
+    variant needs the other direction's best_idx everywhere).
+
+    `nn2_fn(query_block, train) -> (best_idx, best_dist, second_dist)` defaults to
+    the HIP path on this rank's GPU."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if nn2_fn is None:
+        from .matcher import Matcher
+        m = Matcher(torch.cuda.current_device())
+        nn2_fn = m.nn2
+    nq = len(query)
+    lo, hi = shard_range(nq, rank, world)
+    bi, bd, sd = nn2_fn(query[lo:hi], train)
+    per = (nq + world - 1) // world
+    mine = torch.zeros((3, max(per, 1)), dtype=torch.int32, device=device)
+    if hi > lo:
+        mine[0, : hi - lo] = torch.from_numpy(np.ascontiguousarray(bi, dtype=np.int32))
+        mine[1, : hi - lo] = torch.from_numpy(np.ascontiguousarray(bd, dtype=np.int32))
+        mine[2, : hi - lo] = torch.from_numpy(np.ascontiguousarray(sd, dtype=np.int32))
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    full = torch.cat(parts, dim=1)[:, :nq].cpu().numpy()
+    return full[0], full[1], full[2]
