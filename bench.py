@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-extra", action="store_true", help="skip the stereo-latency and 1M x 1M extras")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the collective code path (RCCL) even with one rank: smoke test of the N>1 branch")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo collectives on CPU tensors, every rank on cuda:0")
     return ap.parse_args()
@@ -142,7 +144,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     coll_dev = torch.device("cpu") if a.rehearse else dev  # where collective payloads live
-    if world > 1:
+    multi = world > 1 or a.force_dist
+    if a.force_dist and "RANK" not in os.environ:
+        os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    if multi:
         if a.rehearse:
             dist.init_process_group("gloo")
         else:
@@ -156,7 +161,7 @@ def main():
         db, off = None, None
     t_gen = time.perf_counter() - t_gen
     t_bc = time.perf_counter()
-    if world > 1:
+    if multi:
         d_db, off = sfm_pairs.broadcast_database(db, off, coll_dev)
         d_db = d_db.to(dev)
         torch.cuda.synchronize()
@@ -198,7 +203,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -223,7 +228,7 @@ def main():
     evaluated_rank = float(kinds[0]["comparisons"] + kinds[1]["comparisons"])
     stats = torch.tensor([dt, comps_rank, float(P * a.steps), float(matches), evaluated_rank],
                          dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if multi:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -233,7 +238,7 @@ def main():
 
     # ---- gather of the last step's lists to rank 0 (reported separately, not in `value`) -----
     gather_ms = None
-    if world > 1:
+    if multi:
         torch.cuda.synchronize()
         dist.barrier()
         tg = time.perf_counter()
@@ -244,7 +249,7 @@ def main():
         gather_ms = (time.perf_counter() - tg) * 1e3
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -392,7 +397,7 @@ def main():
         out["extra"] = extra
 
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
