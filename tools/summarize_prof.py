@@ -37,10 +37,11 @@ import json
 vals = {}
 for d, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     p = os.path.join(src, d, "p_results.db")
-    r = q(p, "select avg(value) from counters_collection where counter_name='%s' and kernel_name like '%%scan_kernel<4%%'" % ctr)
-    vals[ctr] = r[0][0]
+    r = q(p, "select kernel_name, avg(value) from counters_collection where counter_name='%s' and "
+             "kernel_name like '%%scan_kernel%%' group by kernel_name order by avg(value) desc" % ctr)
+    kname, vals[ctr] = r[0][0].split("(")[0].replace("void vsm::", ""), r[0][1]
 pairs = 16384
-json.dump({"kernel": "scan_kernel<4,2>", "pairs_per_launch": pairs,
+json.dump({"kernel": kname, "pairs_per_launch": pairs,
            "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
            "bytes_per_pair": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / pairs,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh); raw counter "
