@@ -121,6 +121,29 @@ int vsm_match_pairs_device(vsm_ctx* ctx, const void* d_pairs, size_t n_pairs, in
                            size_t cap_pairs, size_t* out_total);
 
 /*
+ * Replaces visnav::find_matches_landmarks, include/visnav/vo_utils.h:95-187 (called on
+ * every odometry frame, src/odometry.cpp:832 and 887; test/src/test_ex5.cpp:200, 248).
+ * The reference's containers flattened by the caller (the C++ shim
+ * include/visnav_amd/vo_utils_gpu.h does it), all HOST pointers borrowed for the call:
+ *   kp_desc[nk][4], kp_xy[nk][2]   kdl.corner_descriptors, kdl.corners (x, y as double)
+ *   proj_xy[np][2]                 projected_points
+ *   obs_off[np + 1], obs_desc      obs_desc[obs_off[p] .. obs_off[p+1]) = descriptors
+ *       feature_corners.at(fcid).corner_descriptors[fid] for every (fcid, fid) of
+ *       landmarks.at(projected_track_ids[p]).obs (vo_utils.h:150-154); obs_off[0] == 0
+ * out_pairs: (key_point_index, projected_point_index) int32 pairs in the reference's
+ * order (ascending key_point_index); the caller maps the second through
+ * projected_track_ids (vo_utils.h:183-184).  nk pairs always suffice.  The radius gate
+ * `(corner - projected).norm() > match_max_dist_2d` is evaluated in double exactly as the
+ * reference does.  Where the reference would index projected_track_ids[-1] (no candidate,
+ * threshold > 256, dist_2_best <= 1: undefined behaviour) nothing is emitted.
+ */
+int vsm_match_landmarks(vsm_ctx* ctx, const uint64_t* kp_desc, const double* kp_xy, size_t nk,
+                        const double* proj_xy, size_t np, const uint32_t* obs_off,
+                        const uint64_t* obs_desc, double match_max_dist_2d, int threshold,
+                        double dist_2_best, int32_t* out_pairs, size_t cap_pairs,
+                        size_t* out_count);
+
+/*
  * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of
  * the last batched/nn2 call, measured with HIP events on the context's stream,
  * how many launches that was and how many 256-bit comparisons they evaluated.

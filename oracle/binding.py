@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _u64p = C.POINTER(C.c_uint64)
 _i32p = C.POINTER(C.c_int32)
 _u32p = C.POINTER(C.c_uint32)
+_f64p = C.POINTER(C.c_double)
 
 
 def _as_desc(a) -> np.ndarray:
@@ -45,6 +46,12 @@ class _Matcher:
             self._nn2 = getattr(lib, prefix + "_nn2")
             self._nn2.restype = None
             self._nn2.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _i32p, _i32p, _i32p]
+        self._lm = None
+        if hasattr(lib, prefix + "_match_landmarks"):
+            self._lm = getattr(lib, prefix + "_match_landmarks")
+            self._lm.restype = C.c_size_t
+            self._lm.argtypes = [_u64p, _f64p, C.c_size_t, _f64p, C.c_size_t, _u32p, _u64p,
+                                 C.c_double, C.c_int, C.c_double, _i32p, C.c_size_t]
 
     def match(self, d1, d2, threshold=70, dist_2_best=1.2) -> np.ndarray:
         """visnav::matchDescriptors -> int32[n_matches, 2] in reference order."""
@@ -78,6 +85,28 @@ class _Matcher:
                   bi.ctypes.data_as(_i32p), bd.ctypes.data_as(_i32p),
                   sd.ctypes.data_as(_i32p))
         return bi, bd, sd
+
+
+    def match_landmarks(self, kp_desc, kp_xy, proj_xy, obs_off, obs_desc, max_dist_2d=20.0,
+                        threshold=70, dist_2_best=1.2) -> np.ndarray:
+        """visnav::find_matches_landmarks -> int32[n, 2] (keypoint, projected point index);
+        port only."""
+        if self._lm is None:
+            raise NotImplementedError("find_matches_landmarks is only restated in the C port")
+        kp_desc, obs_desc = _as_desc(kp_desc), _as_desc(obs_desc)
+        kp_xy = np.ascontiguousarray(kp_xy, dtype=np.float64).reshape(-1, 2)
+        proj_xy = np.ascontiguousarray(proj_xy, dtype=np.float64).reshape(-1, 2)
+        obs_off = np.ascontiguousarray(obs_off, dtype=np.uint32)
+        assert len(kp_xy) == len(kp_desc) and len(obs_off) == len(proj_xy) + 1
+        assert int(obs_off[-1]) == len(obs_desc)
+        cap = max(1, len(kp_desc))
+        out = np.empty((cap, 2), dtype=np.int32)
+        n = self._lm(kp_desc.ctypes.data_as(_u64p), kp_xy.ctypes.data_as(_f64p), len(kp_desc),
+                     proj_xy.ctypes.data_as(_f64p), len(proj_xy), obs_off.ctypes.data_as(_u32p),
+                     obs_desc.ctypes.data_as(_u64p), float(max_dist_2d), int(threshold),
+                     float(dist_2_best), out.ctypes.data_as(_i32p), cap)
+        assert n <= cap
+        return out[:n].copy()
 
 
 _cache = {}

@@ -4,9 +4,11 @@
 // and its batched call pattern (src/sfm.cpp:1295-1321).  No CPU fallback: every
 // entry point needs a HIP device and fails with VSM_ERR_HIP otherwise.
 #include "vsmatch_kernels.h"
+#include "landmark_kernels.h"
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -155,6 +157,25 @@ void make_accept(int threshold, double dist_2_best, AcceptParams* prm) {
     prm->min_second[b] = (uint16_t)need;
   }
   prm->min_second[257] = 257;
+}
+
+// Radius gate of find_matches_landmarks (vo_utils.h:136-138): `norm > r` with norm =
+// sqrt(squared) correctly rounded is, by monotonicity of sqrt, `squared > T` with T the
+// largest double whose square root is <= r.  NaN r: nothing is ever skipped (T = +inf);
+// negative r: every finite distance is skipped (T = -inf).
+double gate_threshold(double r) {
+  const double inf = std::numeric_limits<double>::infinity();
+  if (std::isnan(r)) return inf;
+  if (r < 0) return -inf;
+  if (std::isinf(r)) return inf;
+  double x = r * r;
+  for (int it = 0; it < 4096 && std::sqrt(x) > r; it++) x = std::nextafter(x, -inf);
+  for (int it = 0; it < 4096; it++) {
+    const double up = std::nextafter(x, inf);
+    if (std::isinf(up) || std::sqrt(up) > r) break;
+    x = up;
+  }
+  return x;
 }
 
 int ev_pair(vsm_ctx* c, hipEvent_t* a, hipEvent_t* b) {
@@ -656,6 +677,86 @@ int vsm_nn2(vsm_ctx* c, const uint64_t* query, size_t nq, const uint64_t* train,
   HIP_TRY(hipMemcpyAsync(best_dist, dout + nq * 4, nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(second_dist, dout + nq * 8, nq * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return VSM_OK;
+}
+
+int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy, size_t nk,
+                        const double* proj_xy, size_t np, const uint32_t* obs_off,
+                        const uint64_t* obs_desc, double match_max_dist_2d, int threshold,
+                        double dist_2_best, int32_t* out_pairs, size_t cap_pairs, size_t* out_count) {
+  VSM_TRY(check_ctx(c));
+  if (!out_count) return fail(VSM_ERR_INVALID, "null out_count");
+  *out_count = 0;
+  if (nk && (!kp_desc || !kp_xy)) return fail(VSM_ERR_INVALID, "null keypoint pointer");
+  if (np && (!proj_xy || !obs_off)) return fail(VSM_ERR_INVALID, "null projected-point pointer");
+  if (nk > VSM_MAX_SET || np > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "set larger than VSM_MAX_SET");
+  if (cap_pairs && !out_pairs) return fail(VSM_ERR_INVALID, "null out_pairs with non-zero capacity");
+  if (nk == 0 || np == 0) return VSM_OK;  // vo_utils.h:104: md.matches.clear(), nothing passes
+  for (size_t p = 0; p < np; p++)
+    if (obs_off[p + 1] < obs_off[p]) return fail(VSM_ERR_INVALID, "obs_off not ascending at projected point %zu", p);
+  if (obs_off[0] != 0) return fail(VSM_ERR_INVALID, "obs_off[0] must be 0");
+  const size_t n_obs = obs_off[np];
+  if (n_obs && !obs_desc) return fail(VSM_ERR_INVALID, "null observation descriptor pointer");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  stats_reset(c);
+  AcceptParams prm;
+  make_accept(threshold, dist_2_best, &prm);
+  const double gate_t = gate_threshold(match_max_dist_2d);
+
+  // One pinned staging block up: [kp_desc | obs_desc | kp_xy | proj_xy | obs_off]
+  // (every section 32-byte aligned), one block down: [count u64, pad | pairs].
+  auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
+  const size_t o_kd = 0, o_od = o_kd + nk * DESC_BYTES, o_kx = o_od + al(std::max<size_t>(n_obs, 1) * DESC_BYTES);
+  const size_t o_px = o_kx + al(nk * 16), o_of = o_px + al(np * 16), up_bytes = o_of + al((np + 1) * 4);
+  const size_t cap = std::min(cap_pairs, nk);
+  const size_t down_bytes = 16 + nk * 8;
+  VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
+  VSM_TRY(c->stage.reserve(up_bytes));
+  VSM_TRY(c->w_out.reserve(down_bytes));
+  char* h = (char*)c->pin.p;
+  memcpy(h + o_kd, kp_desc, nk * DESC_BYTES);
+  if (n_obs) memcpy(h + o_od, obs_desc, n_obs * DESC_BYTES);
+  memcpy(h + o_kx, kp_xy, nk * 16);
+  memcpy(h + o_px, proj_xy, np * 16);
+  memcpy(h + o_of, obs_off, (np + 1) * 4);
+  HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+  char* d = (char*)c->stage.p;
+
+  // Latency-bound: spread the projected points over enough waves to cover the chip
+  // (1024 SIMDs), at least 16 points per wave; 4 waves (= 4 splits) per workgroup.
+  const u32 tiles = (u32)((nk + 63) / 64);
+  u32 splits = std::max<u32>(1, std::min<u32>((u32)((np + 15) / 16), (2048 + tiles - 1) / tiles));
+  splits = std::min<u32>(round_up(splits, 4), 1024);
+  const u32 split_stride = round_up((u32)nk, 64);
+  VSM_TRY(c->scratch.reserve((size_t)split_stride * splits * sizeof(uint2)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->profiling) {
+    VSM_TRY(ev_pair(c, &e0, &e1));
+    c->ev_kind.push_back(0);
+    HIP_TRY(hipEventRecord(e0, c->stream));
+  }
+  hipLaunchKernelGGL(landmark_scan_kernel, dim3(tiles, splits / 4), dim3(256), 0, c->stream,
+                     (const u32x4*)(d + o_kd), (const double2*)(d + o_kx), (u32)nk,
+                     (const double*)(d + o_px), (u32)np, (const u32*)(d + o_of),
+                     (const u32x4*)(d + o_od), gate_t, splits, split_stride, (uint2*)c->scratch.p);
+  HIP_TRY(hipGetLastError());
+  if (c->profiling) HIP_TRY(hipEventRecord(e1, c->stream));
+  c->scan_launches[0]++;
+  hipLaunchKernelGGL(merge_splits_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream,
+                     (uint2*)c->scratch.p, split_stride, splits, split_stride);
+  hipLaunchKernelGGL(landmark_emit_kernel, dim3(1), dim3(256), 0, c->stream, (const uint2*)c->scratch.p,
+                     (u32)nk, prm, (u64*)c->w_out.p, (int2*)((char*)c->w_out.p + 16), (u64)cap);
+  HIP_TRY(hipGetLastError());
+  char* hd = h + up_bytes;
+  HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, 16 + cap * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->profiling) VSM_TRY(stats_collect(c));
+  u64 count;
+  memcpy(&count, hd, 8);
+  *out_count = (size_t)count;
+  if (count > cap_pairs) return fail(VSM_ERR_CAPACITY, "%llu matches need more than cap_pairs=%zu", (unsigned long long)count, cap_pairs);
+  if (count) memcpy(out_pairs, hd + 16, count * 8);
   return VSM_OK;
 }
 

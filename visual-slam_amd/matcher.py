@@ -28,6 +28,7 @@ SYMBOLS = (
     "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
     "vsm_set_profiling",
     "vsm_set_variant",
+    "vsm_match_landmarks",
 )
 
 
@@ -69,6 +70,8 @@ def lib():
             L.vsm_last_scan_stats_kind.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
+            L.vsm_match_landmarks.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_double, C.c_int,
+                                              C.c_double, _vp, _sz, C.POINTER(_sz)]
             _lib = L
     return _lib
 
@@ -191,6 +194,32 @@ class Matcher:
                                             float(dist_2_best), _vp(d_out_offsets), _vp(d_out_pairs),
                                             int(cap), C.byref(total)))
         return total.value
+
+    # -- vo_utils.h:95-187 ------------------------------------------------------
+    def match_landmarks(self, kp_desc, kp_xy, proj_xy, obs_off, obs_desc, match_max_dist_2d: float,
+                        threshold: int = 70, dist_2_best: float = 1.2, track_ids=None) -> np.ndarray:
+        """visnav::find_matches_landmarks on flattened containers (see include/vsmatch.h).
+        Returns int32[n, 2] (key_point_index, projected_point_index), or with `track_ids`
+        (projected_track_ids) int64[n, 2] (featureId, trackId) = md.matches."""
+        kp_desc, obs_desc = as_descriptors(kp_desc), as_descriptors(obs_desc)
+        kp_xy = np.ascontiguousarray(kp_xy, dtype=np.float64).reshape(-1, 2)
+        proj_xy = np.ascontiguousarray(proj_xy, dtype=np.float64).reshape(-1, 2)
+        obs_off = np.ascontiguousarray(obs_off, dtype=np.uint32)
+        if len(kp_xy) != len(kp_desc):
+            raise ValueError("kp_xy and kp_desc differ in length")
+        if obs_off.ndim != 1 or len(obs_off) != len(proj_xy) + 1 or int(obs_off[-1]) != len(obs_desc):
+            raise ValueError("obs_off must be uint32[np + 1] ending at len(obs_desc)")
+        cap = max(1, len(kp_desc))
+        out = np.empty((cap, 2), dtype=np.int32)
+        n = _sz(0)
+        _check(lib().vsm_match_landmarks(self._h, _ptr(kp_desc), _ptr(kp_xy), len(kp_desc), _ptr(proj_xy),
+                                         len(proj_xy), _ptr(obs_off), _ptr(obs_desc), float(match_max_dist_2d),
+                                         int(threshold), float(dist_2_best), _ptr(out), cap, C.byref(n)))
+        got = out[: n.value].copy()
+        if track_ids is None:
+            return got
+        tid = np.asarray(track_ids, dtype=np.int64)
+        return np.stack([got[:, 0].astype(np.int64), tid[got[:, 1]]], axis=1)
 
     # -- measurement ------------------------------------------------------------
     def set_profiling(self, on: bool):

@@ -155,3 +155,56 @@ def all_pairs(n_img: int, frame_of=None) -> np.ndarray:
         keep = f[i] != f[j]
         i, j = i[keep], j[keep]
     return np.ascontiguousarray(np.stack([i, j], axis=1).astype(np.uint32))
+
+
+def _unit(seed: int, stream: int, shape) -> np.ndarray:
+    """Uniform doubles in [0, 1) with 53 random bits."""
+    return (u64(seed, 0x5000 + stream, shape) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def landmark_frame(nk: int, n_proj: int, seed: int, width: float = 752.0, height: float = 480.0,
+                   radius: float = 20.0, max_obs: int = 7, lattice: bool = False):
+    """One odometry frame for find_matches_landmarks (vo_utils.h:95-187).
+
+    `nk` detected keypoints and `n_proj` projected landmarks in a width x height image.
+    About 60 % of the landmarks re-observe a keypoint: they project 0 .. 1.3*radius away
+    from it (so some fall just outside the gate) and their 1..max_obs observation
+    descriptors are noisy copies of that keypoint's descriptor; 10 % are "confusers" that
+    project next to an already used keypoint with a slightly worse descriptor (ratio-test
+    failures, vo_utils.h:179); 5 % have no observations at all; the rest are unrelated.
+    `lattice=True` snaps every coordinate to the integer grid, which puts many
+    (keypoint, landmark) distances EXACTLY on an integer radius (3-4-5 triangles), the
+    boundary of the `>` in vo_utils.h:138.
+
+    Returns (kp_desc uint64[nk,4], kp_xy f64[nk,2], proj_xy f64[n_proj,2],
+             obs_off uint32[n_proj+1], obs_desc uint64[*,4]).
+    """
+    kp_desc = random_descriptors(nk, seed, 20)
+    _plant_intra(kp_desc, seed, 20, 0.02, 0.02)
+    kp_xy = _unit(seed, 1, (nk, 2)) * np.array([width, height])
+    proj_xy = _unit(seed, 2, (n_proj, 2)) * np.array([width, height])
+    kind = _unit(seed, 3, (n_proj,))
+    n_obs = 1 + (u64(seed, 0x6000, (n_proj,)) % np.uint64(max(1, max_obs))).astype(np.int64)
+    n_obs[(kind >= 0.70) & (kind < 0.75)] = 0
+    obs_off = np.zeros(n_proj + 1, dtype=np.uint32)
+    obs_off[1:] = np.cumsum(n_obs)
+    total = int(obs_off[-1])
+    obs_desc = random_descriptors(total, seed, 21)
+    if nk and n_proj:
+        target = (u64(seed, 0x6001, (n_proj,)) % np.uint64(nk)).astype(np.int64)
+        ang = _unit(seed, 4, (n_proj,)) * 2 * np.pi
+        rad = _unit(seed, 5, (n_proj,)) * 1.3 * radius
+        near = kind < 0.70
+        proj_xy[near] = kp_xy[target[near]] + np.stack([np.cos(ang), np.sin(ang)], axis=1)[near] * rad[near, None]
+        owner = np.repeat(np.arange(n_proj), n_obs)
+        strong = flip_masks(total, seed, 30, levels=(3, 4, 5))
+        weak = flip_masks(total, seed, 31, levels=(2, 3))
+        rel = (kind < 0.60)[owner]
+        con = ((kind >= 0.60) & (kind < 0.70))[owner]
+        obs_desc[rel] = kp_desc[target[owner[rel]]] ^ strong[rel]
+        obs_desc[con] = kp_desc[target[owner[con]]] ^ weak[con]
+    if lattice:
+        kp_xy = np.floor(kp_xy)
+        proj_xy = np.floor(proj_xy)
+    return (np.ascontiguousarray(kp_desc), np.ascontiguousarray(kp_xy), np.ascontiguousarray(proj_xy),
+            obs_off, np.ascontiguousarray(obs_desc))
