@@ -328,6 +328,30 @@ def main():
         extra["stereo_1500x1500"] = {"latency_ms_host_to_host": lat * 1e3, "scan_kernel_ms": scan_only,
                                      "matches": int(len(res)), "reference_equivalent_gcomps": 2 * 1500 * 1500 / lat / 1e9,
                                      "note": "host pointers in, host list out: H2D + 6 kernels + D2H, PCIe inclusive"}
+        # next row N1: one odometry frame of find_matches_landmarks
+        # (vo_utils.h:95-187, odometry.cpp:832): 1500 keypoints x 2500 projected landmarks,
+        # radius 20 px (odometry.cpp:177), host pointers in/out; CPU = the C oracle, 1 thread
+        lf = synth.landmark_frame(1500, 2500, a.seed + 5)
+        for _ in range(5):
+            lres = m.match_landmarks(*lf, 20.0, a.threshold, a.ratio)
+        t = time.perf_counter()
+        for _ in range(50):
+            lres = m.match_landmarks(*lf, 20.0, a.threshold, a.ratio)
+        llat = (time.perf_counter() - t) / 50
+        m.set_profiling(True)
+        m.match_landmarks(*lf, 20.0, a.threshold, a.ratio)
+        lscan = m.last_scan_stats()["scan_ms"]
+        m.set_profiling(False)
+        from oracle import binding as _ob
+        t = time.perf_counter()
+        for _ in range(5):
+            lwant = _ob.port().match_landmarks(*lf, 20.0, a.threshold, a.ratio)
+        lcpu = (time.perf_counter() - t) / 5
+        extra["landmarks_1500kp_x_2500lm"] = {
+            "latency_ms_host_to_host": llat * 1e3, "scan_kernel_ms": lscan, "matches": int(len(lres)),
+            "cpu_port_ms_1_thread": lcpu * 1e3, "bit_exact_vs_cpu": bool(np.array_equal(lres, lwant)),
+            "observations": int(lf[3][-1]),
+            "note": "H2D + 3 kernels + D2H, PCIe inclusive; the gate evaluates 3.75 M point pairs in double"}
         # config 3 shape: 164 images (82 stereo frames) of 1200-1500 descriptors, the 13284
         # non-stereo pairs of sfm.cpp:1285-1290 in one batch
         sz = np.random.default_rng(3).integers(1200, 1501, size=164)
