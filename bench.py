@@ -352,6 +352,25 @@ def main():
             "cpu_port_ms_1_thread": lcpu * 1e3, "bit_exact_vs_cpu": bool(np.array_equal(lres, lwant)),
             "observations": int(lf[3][-1]),
             "note": "H2D + 3 kernels + D2H, PCIe inclusive; the gate evaluates 3.75 M point pairs in double"}
+        # next row N2: computeAngles + computeDescriptors (keypoints.h:151-237) for
+        # one 752 x 480 EuRoC-sized frame with 1500 corners; host image in, host descriptors out
+        rng = np.random.default_rng(a.seed)
+        oimg = rng.integers(0, 256, size=(480, 752), dtype=np.uint8)
+        oxy = np.floor(np.stack([rng.uniform(19, 752 - 19, 1500), rng.uniform(19, 480 - 19, 1500)], axis=1))
+        for _ in range(5):
+            oa, od = m.orb_describe(oimg, oxy)
+        t = time.perf_counter()
+        for _ in range(50):
+            oa, od = m.orb_describe(oimg, oxy)
+        olat = (time.perf_counter() - t) / 50
+        t = time.perf_counter()
+        for _ in range(5):
+            ca, cd = _ob.port().orb_describe(oimg, oxy)
+        ocpu = (time.perf_counter() - t) / 5
+        extra["orb_describe_752x480_1500kp"] = {
+            "latency_ms_host_to_host": olat * 1e3, "cpu_port_ms_1_thread": ocpu * 1e3,
+            "bit_exact_vs_cpu": bool(np.array_equal(oa, ca) and np.array_equal(od, cd)),
+            "note": "361 KB image H2D + moments kernel + D2H + host atan2/cos/sin + H2D + descriptor kernel + D2H"}
         # config 3 shape: 164 images (82 stereo frames) of 1200-1500 descriptors, the 13284
         # non-stereo pairs of sfm.cpp:1285-1290 in one batch
         sz = np.random.default_rng(3).integers(1200, 1501, size=164)

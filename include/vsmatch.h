@@ -144,6 +144,23 @@ int vsm_match_landmarks(vsm_ctx* ctx, const uint64_t* kp_desc, const double* kp_
                         size_t* out_count);
 
 /*
+ * Replaces visnav::computeAngles + visnav::computeDescriptors, include/visnav/keypoints.h:
+ * 151-201 and 203-237 (run by detectKeypointsAndDescriptors, keypoints.h:243-244, called at
+ * src/sfm.cpp:1199 and src/odometry.cpp:804-807; test/src/test_ex3.cpp:76-146), i.e.
+ * everything after corner detection.  img: HOST pointer to an 8-bit image, img(x, y) =
+ * img[y * pitch + x] (pangolin::ManagedImage<uint8_t>: ptr, w, h, pitch); corners_xy[n][2]:
+ * kd.corners (x, y as double).  angles_out[n] (may be NULL) = kd.corner_angles: atan2 of the
+ * intensity-centroid moments, or 0 when rotate_features == 0.  desc_out[n][4] (may be NULL:
+ * angles only) = kd.corner_descriptors, packed as above.  With desc_out every corner must lie
+ * at least EDGE_THRESHOLD = 19 pixels inside the image, as detectKeypoints guarantees
+ * (keypoints.h:145); the reference reads outside the image otherwise, this returns
+ * VSM_ERR_INVALID.  atan2 / cos / sin run on the host with the caller's libm.
+ */
+int vsm_orb_describe(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
+                     const double* corners_xy, size_t n, int rotate_features, double* angles_out,
+                     uint64_t* desc_out);
+
+/*
  * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of
  * the last batched/nn2 call, measured with HIP events on the context's stream,
  * how many launches that was and how many 256-bit comparisons they evaluated.

@@ -46,6 +46,15 @@ class _Matcher:
             self._nn2 = getattr(lib, prefix + "_nn2")
             self._nn2.restype = None
             self._nn2.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _i32p, _i32p, _i32p]
+        self._orb_a = self._orb_d = None
+        if hasattr(lib, prefix + "_orb_angles"):
+            _u8p = C.POINTER(C.c_uint8)
+            self._orb_a = getattr(lib, prefix + "_orb_angles")
+            self._orb_a.restype = None
+            self._orb_a.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, _f64p, C.c_size_t, C.c_int, _f64p]
+            self._orb_d = getattr(lib, prefix + "_orb_descriptors")
+            self._orb_d.restype = C.c_int
+            self._orb_d.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, _f64p, _f64p, C.c_size_t, _u64p]
         self._lm = None
         if hasattr(lib, prefix + "_match_landmarks"):
             self._lm = getattr(lib, prefix + "_match_landmarks")
@@ -107,6 +116,28 @@ class _Matcher:
                      float(dist_2_best), out.ctypes.data_as(_i32p), cap)
         assert n <= cap
         return out[:n].copy()
+
+
+    def orb_describe(self, img, corners_xy, rotate_features=True):
+        """visnav::computeAngles + computeDescriptors -> (angles f64[n], desc uint64[n,4]);
+        port only.  Raises ValueError for a corner inside the 19-pixel border."""
+        if self._orb_a is None:
+            raise NotImplementedError("ORB extraction is only restated in the C port")
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        assert img.ndim == 2
+        xy = np.ascontiguousarray(corners_xy, dtype=np.float64).reshape(-1, 2)
+        n = len(xy)
+        ang = np.zeros(n, dtype=np.float64)
+        desc = np.zeros((n, 4), dtype=np.uint64)
+        u8 = C.POINTER(C.c_uint8)
+        h, w = img.shape
+        self._orb_a(img.ctypes.data_as(u8), w, h, img.strides[0], xy.ctypes.data_as(_f64p), n,
+                    1 if rotate_features else 0, ang.ctypes.data_as(_f64p))
+        rc = self._orb_d(img.ctypes.data_as(u8), w, h, img.strides[0], xy.ctypes.data_as(_f64p),
+                         ang.ctypes.data_as(_f64p), n, desc.ctypes.data_as(_u64p))
+        if rc != 0:
+            raise ValueError("corner closer than EDGE_THRESHOLD to the border")
+        return ang, desc
 
 
 _cache = {}

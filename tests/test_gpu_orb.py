@@ -1,0 +1,86 @@
+"""GPU parity of vsm_orb_describe (computeAngles + computeDescriptors, keypoints.h:151-237)
+through the C ABI: the reference's golden vectors (test_ex3.cpp:76-146) and the CPU oracle on
+synthetic images.  Bar: descriptors bit-exact; angles bit-exact against the oracle (same host
+libm, integer moments from the GPU) and within 1e-8 of the reference's JSON (its own test's
+tolerance)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from tests.test_orb_oracle import ex3_image, ex3_kd, synth_corners, synth_image
+
+pytestmark = pytest.mark.gpu
+vsm = importlib.import_module("visual-slam_amd")
+
+
+@pytest.fixture(scope="module")
+def m():
+    with vsm.Matcher(0) as mm:
+        yield mm
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_reference_goldens(m, k):
+    xy, angles, desc = ex3_kd(k)
+    img = ex3_image(k)
+    a, d = m.orb_describe(img, xy, True)
+    assert np.abs(a - angles).max() < 1e-8
+    assert np.array_equal(d, desc)
+    ao, do = binding.port().orb_describe(img, xy, True)
+    assert np.array_equal(a, ao) and np.array_equal(d, do)
+
+
+def test_extraction_then_matching_is_the_reference_pipeline(m):
+    """KeypointsAll (test_ex3.cpp:187-218) minus detection: descriptors extracted on the GPU
+    from both images, matched on the GPU, equal the golden matches.json."""
+    import os
+    from tests import cases
+    d = [m.orb_describe(ex3_image(k), ex3_kd(k)[0])[1] for k in (0, 1)]
+    want = np.load(os.path.join(cases.GOLDEN, "ex3_matches.npy"))
+    assert np.array_equal(m.match(d[0], d[1], 70, 1.2), want)
+
+
+@pytest.mark.parametrize("w,h,n,seed", [(96, 64, 40, 1), (752, 480, 1500, 2), (41, 39, 12, 3), (1920, 1080, 5000, 4),
+                                        (39, 39, 1, 5)])
+def test_synthetic_equal_oracle(m, w, h, n, seed):
+    img = synth_image(w, h, seed)
+    xy = synth_corners(w, h, n, seed) if n > 2 else np.array([[19.5, 19.0]])
+    for rot in (True, False):
+        a, d = m.orb_describe(img, xy, rot)
+        ao, do = binding.port().orb_describe(img, xy, rot)
+        assert np.array_equal(a, ao) and np.array_equal(d, do), (w, h, n, seed, rot)
+
+
+def test_strided_rows_and_angles_only(m):
+    big = synth_image(200, 120, 7)
+    view = big[:, 10:170]  # pitch 200, width 160
+    xy = synth_corners(160, 120, 50, 7)
+    a, d = m.orb_describe(view, xy)
+    ao, do = binding.port().orb_describe(np.ascontiguousarray(view), xy)
+    assert np.array_equal(a, ao) and np.array_equal(d, do)
+    # angles only: corners anywhere, even outside the image (all-zero moments -> atan2(0, 0) = 0)
+    far = np.array([[3.0, 2.0], [159.0, 119.0], [-40.0, 10.0], [500.0, 500.0]])
+    a2, none = m.orb_describe(view, far, True, descriptors=False)
+    assert none is None and a2[3] == 0.0
+    xy_edge = np.array([[3.0, 2.0], [159.0, 119.0], [25.0, 25.0]])
+    import ctypes
+    ang = np.zeros(3)
+    binding.port()._orb_a(np.ascontiguousarray(view).ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 160, 120, 160,
+                          xy_edge.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 3, 1,
+                          ang.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    a3, _ = m.orb_describe(view, xy_edge, True, descriptors=False)
+    assert np.array_equal(a3, ang)
+
+
+def test_errors(m):
+    img = synth_image(96, 64, 5)
+    with pytest.raises(vsm.VsmError) as e:
+        m.orb_describe(img, np.array([[18.9, 30.0]]))
+    assert e.value.code == vsm.matcher.VSM_ERR_INVALID
+    with pytest.raises(vsm.VsmError):
+        m.orb_describe(img, np.array([[float("nan"), 30.0]]), True, descriptors=False)
+    a, d = m.orb_describe(img, np.zeros((0, 2)))
+    assert len(a) == 0 and d.shape == (0, 4)

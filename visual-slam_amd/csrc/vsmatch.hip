@@ -5,6 +5,7 @@
 // entry point needs a HIP device and fails with VSM_ERR_HIP otherwise.
 #include "vsmatch_kernels.h"
 #include "landmark_kernels.h"
+#include "orb_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -757,6 +758,90 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   *out_count = (size_t)count;
   if (count > cap_pairs) return fail(VSM_ERR_CAPACITY, "%llu matches need more than cap_pairs=%zu", (unsigned long long)count, cap_pairs);
   if (count) memcpy(out_pairs, hd + 16, count * 8);
+  return VSM_OK;
+}
+
+int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                     const double* corners_xy, size_t n, int rotate_features, double* angles_out,
+                     uint64_t* desc_out) {
+  VSM_TRY(check_ctx(c));
+  if (n == 0) return VSM_OK;
+  if (!img || !corners_xy) return fail(VSM_ERR_INVALID, "null image or corner pointer");
+  if (!angles_out && !desc_out) return fail(VSM_ERR_INVALID, "both outputs are null");
+  if (width <= 0 || height <= 0 || pitch < (size_t)width || width > 32768 || height > 32768)
+    return fail(VSM_ERR_INVALID, "bad image geometry %d x %d, pitch %zu", width, height, pitch);
+  if (n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "more than VSM_MAX_SET corners");
+  for (size_t i = 0; i < n; i++) {
+    const double x = corners_xy[2 * i], y = corners_xy[2 * i + 1];
+    // `const int cx = p[0]` (keypoints.h:158, 213) is undefined outside the int range
+    if (!(std::fabs(x) < 1073741824.0) || !(std::fabs(y) < 1073741824.0))
+      return fail(VSM_ERR_INVALID, "corner %zu is not finite or out of range", i);
+    if (desc_out) {
+      // computeDescriptors reads up to 19 pixels away (keypoints.h:227-228); the reference only
+      // ever passes corners that detectKeypoints kept (InBounds(.., EDGE_THRESHOLD), :145)
+      const int cx = (int)x, cy = (int)y;
+      if (cx < VSM_ORB_EDGE_THRESHOLD || cx >= width - VSM_ORB_EDGE_THRESHOLD || cy < VSM_ORB_EDGE_THRESHOLD ||
+          cy >= height - VSM_ORB_EDGE_THRESHOLD)
+        return fail(VSM_ERR_INVALID, "corner %zu (%d, %d) is closer than %d pixels to the image border: "
+                    "the reference reads outside the image there", i, cx, cy, VSM_ORB_EDGE_THRESHOLD);
+    }
+  }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  // pinned staging: [image rows packed to `width` | corners | (cos, sin)] up,
+  //                 [moments | descriptors] down
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t img_bytes = (size_t)width * height;
+  const size_t o_img = 0, o_xy = al(img_bytes), o_cs = o_xy + al(n * 16), up_bytes = o_cs + al(n * 16);
+  const size_t o_mom = 0, o_desc = al(n * 8), down_bytes = o_desc + n * DESC_BYTES;
+  VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
+  VSM_TRY(c->stage.reserve(up_bytes));
+  VSM_TRY(c->w_out.reserve(down_bytes));
+  char* h = (char*)c->pin.p;
+  char* hd = h + up_bytes;
+  if (pitch == (size_t)width) memcpy(h + o_img, img, img_bytes);
+  else
+    for (int y = 0; y < height; y++) memcpy(h + o_img + (size_t)y * width, img + (size_t)y * pitch, (size_t)width);
+  memcpy(h + o_xy, corners_xy, n * 16);
+  char* d = (char*)c->stage.p;
+  char* dd = (char*)c->w_out.p;
+  HIP_TRY(hipMemcpyAsync(d, h, o_cs, hipMemcpyHostToDevice, c->stream));
+  double* cs = (double*)(h + o_cs);
+  std::vector<double> ang_local;
+  double* ang = angles_out;
+  if (!ang) {
+    ang_local.resize(n);
+    ang = ang_local.data();
+  }
+  if (rotate_features) {
+    hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n + 3) / 4)), dim3(256), 0, c->stream,
+                       (const uint8_t*)(d + o_img), width, height, (u32)width, (const double2*)(d + o_xy),
+                       (u32)n, (int2*)(dd + o_mom));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hd + o_mom, dd + o_mom, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int32_t* mom = (const int32_t*)(hd + o_mom);
+    for (size_t i = 0; i < n; i++)  // keypoints.h:195, host libm
+      ang[i] = std::atan2((double)mom[2 * i + 1], (double)mom[2 * i]);
+  } else {
+    for (size_t i = 0; i < n; i++) ang[i] = 0;  // keypoints.h:161
+  }
+  if (!desc_out) {
+    if (!rotate_features) HIP_TRY(hipStreamSynchronize(c->stream));
+    return VSM_OK;
+  }
+  for (size_t i = 0; i < n; i++) {  // keypoints.h:219, host libm
+    cs[2 * i] = std::cos(ang[i]);
+    cs[2 * i + 1] = std::sin(ang[i]);
+  }
+  HIP_TRY(hipMemcpyAsync(d + o_cs, h + o_cs, n * 16, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(orb_descriptor_kernel, dim3((u32)n), dim3(256), 0, c->stream,
+                     (const uint8_t*)(d + o_img), width, height, (u32)width, (const double2*)(d + o_xy),
+                     (const double2*)(d + o_cs), (u32)n, (u64*)(dd + o_desc));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(hd + o_desc, dd + o_desc, n * DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(desc_out, hd + o_desc, n * DESC_BYTES);
   return VSM_OK;
 }
 

@@ -29,6 +29,7 @@ SYMBOLS = (
     "vsm_set_profiling",
     "vsm_set_variant",
     "vsm_match_landmarks",
+    "vsm_orb_describe",
 )
 
 
@@ -70,6 +71,7 @@ def lib():
             L.vsm_last_scan_stats_kind.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
+            L.vsm_orb_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp, _vp]
             L.vsm_match_landmarks.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_double, C.c_int,
                                               C.c_double, _vp, _sz, C.POINTER(_sz)]
             _lib = L
@@ -220,6 +222,25 @@ class Matcher:
             return got
         tid = np.asarray(track_ids, dtype=np.int64)
         return np.stack([got[:, 0].astype(np.int64), tid[got[:, 1]]], axis=1)
+
+    # -- keypoints.h:151-237 ------------------------------------------------------
+    def orb_describe(self, img, corners_xy, rotate_features: bool = True, descriptors: bool = True):
+        """visnav::computeAngles + computeDescriptors on an 8-bit image (2-D uint8 array, rows may
+        be strided) -> (corner_angles f64[n], corner_descriptors uint64[n, 4] or None)."""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            img = np.ascontiguousarray(img, dtype=np.uint8)
+            if img.ndim != 2:
+                raise ValueError("image must be 2-D uint8")
+        xy = np.ascontiguousarray(corners_xy, dtype=np.float64).reshape(-1, 2)
+        n = len(xy)
+        ang = np.zeros(n, dtype=np.float64)
+        desc = np.zeros((n, 4), dtype=np.uint64) if descriptors else None
+        h, w = img.shape
+        _check(lib().vsm_orb_describe(self._h, C.c_void_p(img.ctypes.data), w, h, img.strides[0], _ptr(xy), n,
+                                      1 if rotate_features else 0, _ptr(ang),
+                                      _ptr(desc) if descriptors else C.c_void_p(0)))
+        return ang, desc
 
     # -- measurement ------------------------------------------------------------
     def set_profiling(self, on: bool):
