@@ -1,0 +1,90 @@
+// keypoints_orb_gpu.h -- header-only C++ shims for the ORB orientation and descriptor step.
+//
+// Drop-ins for the definitions at /root/reference/include/visnav/keypoints.h:151-201 and 203-237:
+//
+//   void visnav::computeAngles(const pangolin::ManagedImage<uint8_t>& img_raw,
+//                              KeypointsData& kd, bool rotate_features);
+//   void visnav::computeDescriptors(const pangolin::ManagedImage<uint8_t>& img_raw,
+//                                   KeypointsData& kd);
+//
+// Same argument order and meaning; kd.corner_angles / kd.corner_descriptors are resized to
+// kd.corners.size() and filled.  Image and keypoint types are template parameters deduced at
+// the call site (keypoints.h:243-244), so this header needs neither Pangolin nor Eigen.
+// Required members: img_raw.ptr (const uint8_t*), .w, .h, .pitch (bytes per row);
+// kd.corners[i][0], [1]; kd.corner_angles (vector<double>); kd.corner_descriptors
+// (vector<bitset<256>>).  computeAnglesAndDescriptors does both with one image upload.
+// Failures of the GPU path throw std::runtime_error (no CPU fallback); so does a corner
+// closer than EDGE_THRESHOLD = 19 pixels to the border in computeDescriptors, where the
+// reference reads outside the image.
+#pragma once
+
+#include <bitset>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "visnav_amd/keypoints_gpu.h"
+
+namespace visnav {
+namespace vsm_detail {
+
+template <class KeypointsDataT>
+inline const std::vector<double>& flat_corners(const KeypointsDataT& kd) {
+  thread_local std::vector<double> xy;
+  xy.resize(2 * kd.corners.size());
+  for (size_t i = 0; i < kd.corners.size(); i++) {
+    xy[2 * i] = kd.corners[i][0];
+    xy[2 * i + 1] = kd.corners[i][1];
+  }
+  return xy;
+}
+
+inline void orb_check(int rc, const char* what) {
+  if (rc != VSM_OK) throw std::runtime_error(std::string("visnav::") + what + " (GPU): " + vsm_last_error());
+}
+
+}  // namespace vsm_detail
+
+template <class ImageT, class KeypointsDataT>
+inline void computeAngles(const ImageT& img_raw, KeypointsDataT& kd, bool rotate_features) {
+  const size_t n = kd.corners.size();
+  kd.corner_angles.resize(n);  // keypoints.h:153
+  if (n == 0) return;
+  const std::vector<double>& xy = vsm_detail::flat_corners(kd);
+  vsm_detail::orb_check(vsm_orb_angles(vsm_detail::thread_context(), img_raw.ptr, int(img_raw.w), int(img_raw.h),
+                                       size_t(img_raw.pitch), xy.data(), n, rotate_features ? 1 : 0,
+                                       kd.corner_angles.data()),
+                        "computeAngles");
+}
+
+template <class ImageT, class KeypointsDataT>
+inline void computeDescriptors(const ImageT& img_raw, KeypointsDataT& kd) {
+  const size_t n = kd.corners.size();
+  kd.corner_descriptors.resize(n);  // keypoints.h:205
+  if (n == 0) return;
+  if (kd.corner_angles.size() < n) throw std::runtime_error("visnav::computeDescriptors (GPU): corner_angles too short");
+  const std::vector<double>& xy = vsm_detail::flat_corners(kd);
+  vsm_detail::orb_check(
+      vsm_orb_descriptors(vsm_detail::thread_context(), img_raw.ptr, int(img_raw.w), int(img_raw.h),
+                          size_t(img_raw.pitch), xy.data(), kd.corner_angles.data(), n,
+                          reinterpret_cast<uint64_t*>(kd.corner_descriptors.data())),
+      "computeDescriptors");
+}
+
+// keypoints.h:243-244 in one call (one image upload).
+template <class ImageT, class KeypointsDataT>
+inline void computeAnglesAndDescriptors(const ImageT& img_raw, KeypointsDataT& kd, bool rotate_features) {
+  const size_t n = kd.corners.size();
+  kd.corner_angles.resize(n);
+  kd.corner_descriptors.resize(n);
+  if (n == 0) return;
+  const std::vector<double>& xy = vsm_detail::flat_corners(kd);
+  vsm_detail::orb_check(
+      vsm_orb_describe(vsm_detail::thread_context(), img_raw.ptr, int(img_raw.w), int(img_raw.h),
+                       size_t(img_raw.pitch), xy.data(), n, rotate_features ? 1 : 0, kd.corner_angles.data(),
+                       reinterpret_cast<uint64_t*>(kd.corner_descriptors.data())),
+      "computeAnglesAndDescriptors");
+}
+
+}  // namespace visnav

@@ -159,6 +159,15 @@ int vsm_match_landmarks(vsm_ctx* ctx, const uint64_t* kp_desc, const double* kp_
 int vsm_orb_describe(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
                      const double* corners_xy, size_t n, int rotate_features, double* angles_out,
                      uint64_t* desc_out);
+/* The two halves as the reference splits them: visnav::computeAngles (keypoints.h:151-201;
+ * corners may lie anywhere, pixels outside the image are skipped) and
+ * visnav::computeDescriptors with the angles given by the caller (keypoints.h:203-237;
+ * border rule as above). */
+int vsm_orb_angles(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
+                   const double* corners_xy, size_t n, int rotate_features, double* angles_out);
+int vsm_orb_descriptors(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
+                        const double* corners_xy, const double* angles, size_t n,
+                        uint64_t* desc_out);
 
 /*
  * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of

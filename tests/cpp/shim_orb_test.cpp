@@ -1,0 +1,75 @@
+// shim_orb_test.cpp -- the reference's KeypointAngles / KeypointDescriptors tests
+// (test_ex3.cpp:76-146) minus detection, against include/visnav_amd/keypoints_orb_gpu.h with
+// stand-ins for pangolin::ManagedImage<uint8_t> and KeypointsData (same members).
+// usage: shim_orb_test <dir>  with img.bin (w*h bytes), dims.bin (2 x int32: w, h), corners.bin,
+//        angles.bin, desc.bin written by tests/test_gpu_orb.py
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "visnav_amd/keypoints_orb_gpu.h"
+
+struct Image {  // pangolin::Image<uint8_t>: pitch, ptr, w, h
+  size_t pitch;
+  const uint8_t* ptr;
+  size_t w, h;
+};
+struct KeypointsData {  // common_types.h:112-122
+  std::vector<std::array<double, 2>> corners;
+  std::vector<double> corner_angles;
+  std::vector<std::bitset<256>> corner_descriptors;
+};
+
+template <class T>
+static std::vector<T> raw(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  std::vector<char> all((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<T> v(all.size() / sizeof(T));
+  std::memcpy((void*)v.data(), all.data(), v.size() * sizeof(T));
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 2) return 2;
+  const std::string dir = std::string(argv[1]) + "/";
+  auto pix = raw<uint8_t>(dir + "img.bin");
+  auto dims = raw<int32_t>(dir + "dims.bin");
+  auto want_desc = raw<std::bitset<256>>(dir + "desc.bin");
+  auto want_ang = raw<double>(dir + "angles.bin");
+  KeypointsData kd;
+  kd.corners = raw<std::array<double, 2>>(dir + "corners.bin");
+  if (dims.size() != 2 || pix.size() != size_t(dims[0]) * dims[1] || kd.corners.size() != want_desc.size()) return 2;
+  Image img{size_t(dims[0]), pix.data(), size_t(dims[0]), size_t(dims[1])};
+
+  visnav::computeAngles(img, kd, true);   // keypoints.h:243
+  visnav::computeDescriptors(img, kd);    // keypoints.h:244
+  for (size_t i = 0; i < want_ang.size(); i++)
+    if (!(std::fabs(kd.corner_angles[i] - want_ang[i]) < 1e-8)) {  // test_ex3.cpp:100-103
+      std::fprintf(stderr, "FAIL: angle %zu\n", i);
+      return 1;
+    }
+  if (kd.corner_descriptors != want_desc) {
+    std::fprintf(stderr, "FAIL: descriptors\n");
+    return 1;
+  }
+  KeypointsData kd2;
+  kd2.corners = kd.corners;
+  visnav::computeAnglesAndDescriptors(img, kd2, true);
+  if (kd2.corner_descriptors != want_desc || kd2.corner_angles != kd.corner_angles) return 1;
+  visnav::computeAngles(img, kd2, false);
+  for (double a : kd2.corner_angles)
+    if (a != 0) return 1;
+  bool threw = false;
+  kd2.corners[0] = {3.0, 3.0};
+  try {
+    visnav::computeDescriptors(img, kd2);
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  if (!threw) return 1;
+  std::printf("orb shim ok: %zu keypoints, angles and descriptors equal the reference's golden kd0.json\n",
+              want_desc.size());
+  return 0;
+}

@@ -84,3 +84,26 @@ def test_errors(m):
         m.orb_describe(img, np.array([[float("nan"), 30.0]]), True, descriptors=False)
     a, d = m.orb_describe(img, np.zeros((0, 2)))
     assert len(a) == 0 and d.shape == (0, 4)
+
+
+def test_split_entry_points_and_cpp_shim(m, tmp_path):
+    """computeAngles / computeDescriptors as separate calls (keypoints.h:243-244), from Python
+    and through the C++ shim with stand-in Pangolin/KeypointsData types (binary built by build())."""
+    import os
+    import subprocess
+    from tests import cases
+    xy, angles, desc = ex3_kd(0)
+    img = ex3_image(0)
+    a, _ = m.orb_describe(img, xy, True, descriptors=False)
+    assert np.array_equal(m.orb_descriptors(img, xy, a), desc)
+    assert np.array_equal(m.orb_descriptors(img, xy, angles), desc)  # the JSON's angles (1 ulp off in one row)
+    assert not np.array_equal(m.orb_descriptors(img, xy, np.zeros(len(xy))), desc)
+    exe = os.path.join(os.path.dirname(cases.GOLDEN.rstrip("/")), "cpp", "shim_orb_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    np.ascontiguousarray(img).tofile(str(tmp_path / "img.bin"))
+    np.array([img.shape[1], img.shape[0]], np.int32).tofile(str(tmp_path / "dims.bin"))
+    xy.tofile(str(tmp_path / "corners.bin"))
+    angles.tofile(str(tmp_path / "angles.bin"))
+    desc.tofile(str(tmp_path / "desc.bin"))
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr

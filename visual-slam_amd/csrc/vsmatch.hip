@@ -761,9 +761,9 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   return VSM_OK;
 }
 
-int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
-                     const double* corners_xy, size_t n, int rotate_features, double* angles_out,
-                     uint64_t* desc_out) {
+static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                    const double* corners_xy, size_t n, int rotate_features, const double* angles_in,
+                    double* angles_out, uint64_t* desc_out) {
   VSM_TRY(check_ctx(c));
   if (n == 0) return VSM_OK;
   if (!img || !corners_xy) return fail(VSM_ERR_INVALID, "null image or corner pointer");
@@ -813,7 +813,9 @@ int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size
     ang_local.resize(n);
     ang = ang_local.data();
   }
-  if (rotate_features) {
+  if (angles_in) {
+    for (size_t i = 0; i < n; i++) ang[i] = angles_in[i];  // computeDescriptors: kd.corner_angles as given
+  } else if (rotate_features) {
     hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n + 3) / 4)), dim3(256), 0, c->stream,
                        (const uint8_t*)(d + o_img), width, height, (u32)width, (const double2*)(d + o_xy),
                        (u32)n, (int2*)(dd + o_mom));
@@ -827,7 +829,7 @@ int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size
     for (size_t i = 0; i < n; i++) ang[i] = 0;  // keypoints.h:161
   }
   if (!desc_out) {
-    if (!rotate_features) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (angles_in || !rotate_features) HIP_TRY(hipStreamSynchronize(c->stream));
     return VSM_OK;
   }
   for (size_t i = 0; i < n; i++) {  // keypoints.h:219, host libm
@@ -843,6 +845,24 @@ int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(desc_out, hd + o_desc, n * DESC_BYTES);
   return VSM_OK;
+}
+
+int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                     const double* corners_xy, size_t n, int rotate_features, double* angles_out,
+                     uint64_t* desc_out) {
+  return orb_impl(c, img, width, height, pitch, corners_xy, n, rotate_features, nullptr, angles_out, desc_out);
+}
+
+int vsm_orb_angles(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                   const double* corners_xy, size_t n, int rotate_features, double* angles_out) {
+  if (n && !angles_out) return fail(VSM_ERR_INVALID, "null angles_out");
+  return orb_impl(c, img, width, height, pitch, corners_xy, n, rotate_features, nullptr, angles_out, nullptr);
+}
+
+int vsm_orb_descriptors(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                        const double* corners_xy, const double* angles, size_t n, uint64_t* desc_out) {
+  if (n && (!angles || !desc_out)) return fail(VSM_ERR_INVALID, "null angles or desc_out");
+  return orb_impl(c, img, width, height, pitch, corners_xy, n, 1, angles, nullptr, desc_out);
 }
 
 }  // extern "C"

@@ -29,7 +29,7 @@ SYMBOLS = (
     "vsm_set_profiling",
     "vsm_set_variant",
     "vsm_match_landmarks",
-    "vsm_orb_describe",
+    "vsm_orb_describe", "vsm_orb_angles", "vsm_orb_descriptors",
 )
 
 
@@ -72,6 +72,8 @@ def lib():
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
             L.vsm_orb_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp, _vp]
+            L.vsm_orb_angles.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp]
+            L.vsm_orb_descriptors.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _vp, _sz, _vp]
             L.vsm_match_landmarks.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_double, C.c_int,
                                               C.c_double, _vp, _sz, C.POINTER(_sz)]
             _lib = L
@@ -241,6 +243,19 @@ class Matcher:
                                       1 if rotate_features else 0, _ptr(ang),
                                       _ptr(desc) if descriptors else C.c_void_p(0)))
         return ang, desc
+
+    def orb_descriptors(self, img, corners_xy, angles) -> np.ndarray:
+        """visnav::computeDescriptors with caller-given angles (keypoints.h:203-237)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        xy = np.ascontiguousarray(corners_xy, dtype=np.float64).reshape(-1, 2)
+        ang = np.ascontiguousarray(angles, dtype=np.float64)
+        if len(ang) != len(xy):
+            raise ValueError("angles and corners differ in length")
+        desc = np.zeros((len(xy), 4), dtype=np.uint64)
+        h, w = img.shape
+        _check(lib().vsm_orb_descriptors(self._h, C.c_void_p(img.ctypes.data), w, h, img.strides[0], _ptr(xy),
+                                         _ptr(ang), len(xy), _ptr(desc)))
+        return desc
 
     # -- measurement ------------------------------------------------------------
     def set_profiling(self, on: bool):
