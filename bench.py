@@ -432,11 +432,23 @@ def main():
         t = time.perf_counter() - t
         st = m.last_scan_stats()
         m.set_profiling(False)
-        bd, sd = o[1].cpu().numpy(), o[2].cpu().numpy()
+        bi, bd, sd = o[0].cpu().numpy(), o[1].cpu().numpy(), o[2].cpu().numpy()
+        # CPU leg for this config: a 1024-query slice against the full 1M train
+        # set on one host core, extrapolated linearly; the slice also checks the GPU result
+        n_slice = 1024
+        t_cpu = time.perf_counter()
+        cbi, cbd, csd = _ob.port().nn2(qa[:n_slice], tb)
+        t_cpu = time.perf_counter() - t_cpu
+        nn2_exact = bool(np.array_equal(cbi, bi[:n_slice]) and np.array_equal(cbd, bd[:n_slice])
+                         and np.array_equal(csd, sd[:n_slice]))
         extra["nn2_1Mx1M"] = {"seconds": t, "gcomps": n * n / t / 1e9, "kernel_ms": st["scan_ms"],
                               "roofline_frac": n * float(n) * 16 / (st["scan_ms"] * 1e-3) / 1e12 / PEAK_TLANEOPS,
                               "frac_of_nominal_64_lanes_per_clk_peak": n * float(n) * 16 / (st["scan_ms"] * 1e-3) / 1e12 / NOMINAL_TLANEOPS,
-                              "accepted_thr70_ratio1.2": int(((bd < 70) & (1.2 * bd <= sd)).sum())}
+                              "accepted_thr70_ratio1.2": int(((bd < 70) & (1.2 * bd <= sd)).sum()),
+                              "cpu_port_1_thread_gcomps": n_slice * float(n) / t_cpu / 1e9,
+                              "cpu_sample": f"{n_slice} queries x 1M train, {t_cpu:.1f} s on 1 core (extrapolates to "
+                                            f"{t_cpu * n / n_slice / 3600:.2f} core-hours for 1M x 1M)",
+                              "bit_exact_vs_cpu_on_slice": nn2_exact}
         out["extra"] = extra
 
     print(json.dumps(out))

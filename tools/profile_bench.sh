@@ -11,4 +11,6 @@ timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- pytho
 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p -- python3 $ARGS > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 $ARGS > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 $ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+# Pass 5: kernel trace of a short run WITH the extras (single stereo pair, landmarks, ORB, 1M x 1M)
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_extras -o t -- python3 bench.py --steps 1 --warmup 1 --cpu-pairs 0 --pairs 4096 > $OUT/trace_extras.json 2> $OUT/trace_extras.err
 find $OUT -type f | head -50

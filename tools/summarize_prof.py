@@ -19,6 +19,15 @@ with open(os.path.join(dst, "kernel_trace_stats.txt"), "w") as f:
     for name, calls, total, avg, pct in q(os.path.join(src, "trace", "t_results.db"), "select * from top_kernels"):
         f.write(f"{name.split('(')[0]:60s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:8.3f}\n")
 
+ex = os.path.join(src, "trace_extras", "t_results.db")
+if os.path.exists(ex):
+    with open(os.path.join(dst, "kernel_trace_stats_extras.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 1 --cpu-pairs 0 --pairs 4096\n")
+        f.write("# (with the extras: stereo pair, find_matches_landmarks frame, ORB frame, config-3 shape, dense overlap, 1M x 1M)\n")
+        f.write("# columns: kernel | calls | total_us | avg_us | percent\n")
+        for name, calls, total, avg, pct in q(ex, "select * from top_kernels"):
+            f.write(f"{name.split('(')[0]:60s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:8.3f}\n")
+
 with open(os.path.join(dst, "pmc_counters.txt"), "w") as f:
     f.write("# rocprofv3 --pmc <counters> (one run per group) -- same command; per-dispatch averages\n")
     f.write("# columns: kernel | counter | dispatches | avg value per dispatch\n")
