@@ -371,6 +371,26 @@ def main():
             "latency_ms_host_to_host": olat * 1e3, "cpu_port_ms_1_thread": ocpu * 1e3,
             "bit_exact_vs_cpu": bool(np.array_equal(oa, ca) and np.array_equal(od, cd)),
             "note": "361 KB image H2D + moments kernel + D2H + host atan2/cos/sin + H2D + descriptor kernel + D2H"}
+        # the whole front end for one frame: detectKeypointsAndDescriptors (keypoints.h:239-245) on a
+        # textured 752 x 480 image, num_features 1500 (sfm.cpp:197), host image in, host kd out
+        yy, xx = np.indices((480, 752))
+        tex = rng.integers(0, 256, size=(480 // 6 + 2, 752 // 6 + 2)).astype(np.float64)
+        timg = np.clip(np.kron(tex, np.ones((6, 6)))[:480, :752] * 0.8 + rng.integers(0, 50, (480, 752)), 0, 255).astype(np.uint8)
+        for _ in range(5):
+            dxy, da, dd = m.detect_and_describe(timg, 1500, True)
+        t = time.perf_counter()
+        for _ in range(30):
+            dxy, da, dd = m.detect_and_describe(timg, 1500, True)
+        dlat = (time.perf_counter() - t) / 30
+        t = time.perf_counter()
+        cxy = _ob.port().detect_keypoints(timg, 1500)
+        ca2, cd2 = _ob.port().orb_describe(timg, cxy)
+        dcpu = time.perf_counter() - t
+        extra["detect_and_describe_752x480"] = {
+            "latency_ms_host_to_host": dlat * 1e3, "corners": int(len(dxy)), "cpu_port_ms_1_thread": dcpu * 1e3,
+            "bit_exact_vs_cpu": bool(np.array_equal(dxy, cxy) and np.array_equal(da, ca2) and np.array_equal(dd, cd2)),
+            "note": "Sobel/min-eigenvalue/local-maxima kernels + host ordering and min-distance pass + ORB kernels; "
+                    "the CPU figure is the plain-C port, not OpenCV's SIMD code"}
         # config 3 shape: 164 images (82 stereo frames) of 1200-1500 descriptors, the 13284
         # non-stereo pairs of sfm.cpp:1285-1290 in one batch
         sz = np.random.default_rng(3).integers(1200, 1501, size=164)

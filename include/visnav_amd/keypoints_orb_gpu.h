@@ -1,7 +1,14 @@
-// keypoints_orb_gpu.h -- header-only C++ shims for the ORB orientation and descriptor step.
+// keypoints_orb_gpu.h -- header-only C++ shims for corner detection and the ORB orientation
+// and descriptor step.
 //
-// Drop-ins for the definitions at /root/reference/include/visnav/keypoints.h:151-201 and 203-237:
+// Drop-ins for the definitions at /root/reference/include/visnav/keypoints.h:133-149, 151-201,
+// 203-237 and 239-245:
 //
+//   void visnav::detectKeypoints(const pangolin::ManagedImage<uint8_t>& img_raw,
+//                                KeypointsData& kd, int num_features);
+//   void visnav::detectKeypointsAndDescriptors(const pangolin::ManagedImage<uint8_t>& img_raw,
+//                                              KeypointsData& kd, int num_features,
+//                                              bool rotate_features);
 //   void visnav::computeAngles(const pangolin::ManagedImage<uint8_t>& img_raw,
 //                              KeypointsData& kd, bool rotate_features);
 //   void visnav::computeDescriptors(const pangolin::ManagedImage<uint8_t>& img_raw,
@@ -22,6 +29,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "visnav_amd/keypoints_gpu.h"
@@ -70,6 +78,47 @@ inline void computeDescriptors(const ImageT& img_raw, KeypointsDataT& kd) {
                           size_t(img_raw.pitch), xy.data(), kd.corner_angles.data(), n,
                           reinterpret_cast<uint64_t*>(kd.corner_descriptors.data())),
       "computeDescriptors");
+}
+
+// keypoints.h:133-149: cv::goodFeaturesToTrack(image, points, num_features, 0.01, 8) + the
+// EDGE_THRESHOLD filter; clears angles and descriptors like the reference (140-142).
+template <class ImageT, class KeypointsDataT>
+inline void detectKeypoints(const ImageT& img_raw, KeypointsDataT& kd, int num_features) {
+  kd.corners.clear();
+  kd.corner_angles.clear();
+  kd.corner_descriptors.clear();
+  thread_local std::vector<double> xy;
+  size_t cap = num_features > 0 ? size_t(num_features) : size_t(img_raw.w) * size_t(img_raw.h), count = 0;
+  xy.resize(2 * (cap ? cap : 1));
+  vsm_detail::orb_check(vsm_detect_keypoints(vsm_detail::thread_context(), img_raw.ptr, int(img_raw.w),
+                                             int(img_raw.h), size_t(img_raw.pitch), num_features, xy.data(), cap,
+                                             &count),
+                        "detectKeypoints");
+  using Corner = typename std::decay<decltype(kd.corners[0])>::type;
+  for (size_t i = 0; i < count; i++) kd.corners.push_back(Corner{xy[2 * i], xy[2 * i + 1]});
+}
+
+// keypoints.h:239-245 with one image upload for all three stages.
+template <class ImageT, class KeypointsDataT>
+inline void detectKeypointsAndDescriptors(const ImageT& img_raw, KeypointsDataT& kd, int num_features,
+                                          bool rotate_features) {
+  kd.corners.clear();
+  thread_local std::vector<double> xy;
+  size_t cap = num_features > 0 ? size_t(num_features) : size_t(img_raw.w) * size_t(img_raw.h), count = 0;
+  if (cap == 0) cap = 1;
+  xy.resize(2 * cap);
+  kd.corner_angles.resize(cap);
+  kd.corner_descriptors.resize(cap);
+  vsm_detail::orb_check(
+      vsm_detect_and_describe(vsm_detail::thread_context(), img_raw.ptr, int(img_raw.w), int(img_raw.h),
+                              size_t(img_raw.pitch), num_features, rotate_features ? 1 : 0, xy.data(),
+                              kd.corner_angles.data(), reinterpret_cast<uint64_t*>(kd.corner_descriptors.data()),
+                              cap, &count),
+      "detectKeypointsAndDescriptors");
+  kd.corner_angles.resize(count);
+  kd.corner_descriptors.resize(count);
+  using Corner = typename std::decay<decltype(kd.corners[0])>::type;
+  for (size_t i = 0; i < count; i++) kd.corners.push_back(Corner{xy[2 * i], xy[2 * i + 1]});
 }
 
 // keypoints.h:243-244 in one call (one image upload).

@@ -170,6 +170,31 @@ int vsm_orb_descriptors(vsm_ctx* ctx, const uint8_t* img, int width, int height,
                         uint64_t* desc_out);
 
 /*
+ * Replaces visnav::detectKeypoints, include/visnav/keypoints.h:133-149:
+ * cv::goodFeaturesToTrack(image, points, num_features, 0.01, 8) (OpenCV, a system dependency
+ * of the reference) followed by the InBounds(x, y, EDGE_THRESHOLD = 19) filter.
+ * corners_out[cap][2] = kd.corners in detection order (strongest first), *out_count their
+ * number; VSM_ERR_CAPACITY (with *out_count = the need) if cap is too small --
+ * num_features always suffices when it is > 0 (0 = no limit, as in OpenCV).
+ */
+int vsm_detect_keypoints(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
+                         int num_features, double* corners_out, size_t cap, size_t* out_count);
+/* The OpenCV call alone, with its parameters (blockSize 3, gradientSize 3, no mask, no
+ * Harris -- the defaults the reference uses); no border filter. */
+int vsm_good_features_to_track(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
+                               int max_corners, double quality_level, double min_distance,
+                               double* corners_out, size_t cap, size_t* out_count);
+/*
+ * Replaces visnav::detectKeypointsAndDescriptors, keypoints.h:239-245 (called at
+ * src/sfm.cpp:1199, src/odometry.cpp:804-807, test/src/test_ex3.cpp:82-83, 193-194):
+ * detection, angles and descriptors with one image upload.  corners_out[cap][2],
+ * angles_out[cap], desc_out[cap][4]; the first *out_count entries are filled.
+ */
+int vsm_detect_and_describe(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
+                            int num_features, int rotate_features, double* corners_out,
+                            double* angles_out, uint64_t* desc_out, size_t cap, size_t* out_count);
+
+/*
  * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of
  * the last batched/nn2 call, measured with HIP events on the context's stream,
  * how many launches that was and how many 256-bit comparisons they evaluated.

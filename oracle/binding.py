@@ -55,6 +55,18 @@ class _Matcher:
             self._orb_d = getattr(lib, prefix + "_orb_descriptors")
             self._orb_d.restype = C.c_int
             self._orb_d.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, _f64p, _f64p, C.c_size_t, _u64p]
+        self._gftt = None
+        if hasattr(lib, prefix + "_gftt"):
+            _u8p = C.POINTER(C.c_uint8)
+            self._gftt = getattr(lib, prefix + "_gftt")
+            self._gftt.restype = C.c_long
+            self._gftt.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double, _f64p, C.c_size_t]
+            self._detect = getattr(lib, prefix + "_detect_keypoints")
+            self._detect.restype = C.c_long
+            self._detect.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, _f64p, C.c_size_t]
+            self._mineig = getattr(lib, prefix + "_gftt_mineig")
+            self._mineig.restype = C.c_int
+            self._mineig.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_float)]
         self._lm = None
         if hasattr(lib, prefix + "_match_landmarks"):
             self._lm = getattr(lib, prefix + "_match_landmarks")
@@ -117,6 +129,35 @@ class _Matcher:
         assert n <= cap
         return out[:n].copy()
 
+
+    def gftt(self, img, max_corners=1500, quality=0.01, min_distance=8.0) -> np.ndarray:
+        """cv::goodFeaturesToTrack -> float64[n, 2] (x, y) in detection order; port only."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros((max(1, w * h), 2), dtype=np.float64)
+        n = self._gftt(img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, img.strides[0], int(max_corners),
+                       float(quality), float(min_distance), out.ctypes.data_as(_f64p), len(out))
+        assert 0 <= n <= len(out)
+        return out[:n].copy()
+
+    def detect_keypoints(self, img, num_features=1500) -> np.ndarray:
+        """visnav::detectKeypoints -> kd.corners float64[n, 2]; port only."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        out = np.zeros((max(1, w * h), 2), dtype=np.float64)
+        n = self._detect(img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, img.strides[0], int(num_features),
+                         out.ctypes.data_as(_f64p), len(out))
+        assert 0 <= n <= len(out)
+        return out[:n].copy()
+
+    def gftt_mineig(self, img) -> np.ndarray:
+        """The minimum-eigenvalue map of cv::cornerMinEigenVal(img, 3, 3) -> float32[h, w]."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        eig = np.zeros((h, w), dtype=np.float32)
+        assert self._mineig(img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, img.strides[0],
+                            eig.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        return eig
 
     def orb_describe(self, img, corners_xy, rotate_features=True):
         """visnav::computeAngles + computeDescriptors -> (angles f64[n], desc uint64[n,4]);

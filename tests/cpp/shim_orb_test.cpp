@@ -32,7 +32,8 @@ static std::vector<T> raw(const std::string& path) {
 }
 
 int main(int argc, char** argv) {
-  if (argc != 2) return 2;
+  if (argc != 2 && argc != 3) return 2;
+  const bool detect = argc == 3;
   const std::string dir = std::string(argv[1]) + "/";
   auto pix = raw<uint8_t>(dir + "img.bin");
   auto dims = raw<int32_t>(dir + "dims.bin");
@@ -43,6 +44,22 @@ int main(int argc, char** argv) {
   if (dims.size() != 2 || pix.size() != size_t(dims[0]) * dims[1] || kd.corners.size() != want_desc.size()) return 2;
   Image img{size_t(dims[0]), pix.data(), size_t(dims[0]), size_t(dims[1])};
 
+  if (detect) {  // KeypointAngles / KeypointDescriptors incl. detection (test_ex3.cpp:82, 117)
+    KeypointsData kdd, kdc;
+    kdd.corner_angles.push_back(1.0);
+    visnav::detectKeypoints(img, kdc, 1500);
+    visnav::detectKeypointsAndDescriptors(img, kdd, 1500, true);
+    if (kdc.corners != kd.corners || !kdc.corner_angles.empty() || kdd.corners != kd.corners ||
+        kdd.corner_descriptors != want_desc || kdd.corner_angles.size() != want_ang.size()) {
+      std::fprintf(stderr, "FAIL: detection (%zu corners, want %zu)\n", kdd.corners.size(), kd.corners.size());
+      return 1;
+    }
+    for (size_t i = 0; i < want_ang.size(); i++)
+      if (!(std::fabs(kdd.corner_angles[i] - want_ang[i]) < 1e-8)) return 1;
+    std::printf("detect shim ok: %zu corners, descriptors and angles equal the reference's golden file\n",
+                kdd.corners.size());
+    return 0;
+  }
   visnav::computeAngles(img, kd, true);   // keypoints.h:243
   visnav::computeDescriptors(img, kd);    // keypoints.h:244
   for (size_t i = 0; i < want_ang.size(); i++)

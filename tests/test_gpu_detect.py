@@ -1,0 +1,103 @@
+"""GPU parity of vsm_detect_keypoints / vsm_good_features_to_track / vsm_detect_and_describe
+(detectKeypoints and detectKeypointsAndDescriptors, keypoints.h:133-149, 239-245) through the C
+ABI: the reference's golden corner lists and the CPU oracle.  Bar: identical corner lists
+(positions and order), descriptors bit-exact, angles as in tests/test_gpu_orb.py."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding
+from tests import cases
+from tests.test_gftt_oracle import GFTT_CASES
+from tests.test_orb_oracle import ex3_image, ex3_kd, synth_image
+
+pytestmark = pytest.mark.gpu
+vsm = importlib.import_module("visual-slam_amd")
+
+
+@pytest.fixture(scope="module")
+def m():
+    with vsm.Matcher(0) as mm:
+        yield mm
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_reference_corner_lists(m, k):
+    want = ex3_kd(k)[0]
+    got = m.detect_keypoints(ex3_image(k), 1500)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    few = m.detect_keypoints(ex3_image(k), 100)
+    assert np.array_equal(few, binding.port().detect_keypoints(ex3_image(k), 100))
+
+
+def test_keypoints_all_on_the_gpu(m):
+    """The reference's KeypointsAll test (test_ex3.cpp:187-218): both images through
+    detectKeypointsAndDescriptors and matchDescriptors(70, 1.2) -- every stage on the GPU --
+    give the golden kd0.json / kd1.json / matches.json."""
+    d = []
+    for k in (0, 1):
+        xy, ang, desc = m.detect_and_describe(ex3_image(k), 1500, True)
+        wxy, wang, wdesc = ex3_kd(k)
+        assert np.array_equal(xy, wxy) and np.abs(ang - wang).max() < 1e-8 and np.array_equal(desc, wdesc)
+        d.append(desc)
+    want = np.load(os.path.join(cases.GOLDEN, "ex3_matches.npy"))
+    assert np.array_equal(m.match(d[0], d[1], 70, 1.2), want)
+
+
+@pytest.mark.parametrize("case", GFTT_CASES + [(752, 480, 21, 1500, 0.01, 8.0), (1920, 1080, 22, 5000, 0.01, 8.0),
+                                               (1000, 31, 23, 0, 0.02, 1.0), (640, 480, 24, 0, 0.01, 0.0)])
+def test_good_features_equal_oracle(m, case):
+    w, h, seed, mc, q, md = case
+    img = synth_image(w, h, seed) if min(w, h) >= 8 else np.random.default_rng(seed).integers(0, 256, (h, w)).astype(np.uint8)
+    want = binding.port().gftt(img, mc, q, md)
+    got = m.good_features_to_track(img, mc, q, md)
+    assert got.shape == want.shape and np.array_equal(got, want), (case, len(got), len(want))
+
+
+def test_noise_flat_and_tie_images(m):
+    o = binding.port()
+    noise = np.random.default_rng(5).integers(0, 256, (300, 400)).astype(np.uint8)  # ~1/9 of the pixels are local maxima
+    assert np.array_equal(m.good_features_to_track(noise, 0, 0.01, 2.0), o.gftt(noise, 0, 0.01, 2.0))
+    assert np.array_equal(m.detect_keypoints(noise, 1500), o.detect_keypoints(noise, 1500))
+    assert len(m.good_features_to_track(np.full((40, 50), 77, np.uint8), 100)) == 0
+    yy, xx = np.indices((48, 64))
+    chk = ((yy // 8 + xx // 8) % 2 * 255).astype(np.uint8)  # exactly equal eigenvalues: the tie order matters
+    got = m.good_features_to_track(chk, 0, 0.01, 4.0)
+    assert len(got) > 10 and np.array_equal(got, o.gftt(chk, 0, 0.01, 4.0))
+    xy, ang, desc = m.detect_and_describe(noise[:, 3:395], 800, True)       # strided rows
+    oxy = o.detect_keypoints(np.ascontiguousarray(noise[:, 3:395]), 800)
+    oa, od = o.orb_describe(np.ascontiguousarray(noise[:, 3:395]), oxy)
+    assert np.array_equal(xy, oxy) and np.array_equal(ang, oa) and np.array_equal(desc, od)
+
+
+def test_errors_and_capacity(m):
+    import ctypes as C
+    img = synth_image(96, 64, 1)
+    with pytest.raises(vsm.VsmError):
+        m.good_features_to_track(img, 10, 0.0, 8.0)      # CV_Assert(qualityLevel > 0)
+    with pytest.raises(vsm.VsmError):
+        m.good_features_to_track(img, 10, 0.01, -1.0)
+    n = C.c_size_t(0)
+    out = np.zeros((2, 2))
+    rc = vsm.matcher.lib().vsm_detect_keypoints(m._h, C.c_void_p(img.ctypes.data), 96, 64, 96, 0, C.c_void_p(out.ctypes.data),
+                                                2, C.byref(n))
+    assert rc == vsm.matcher.VSM_ERR_CAPACITY and n.value == len(binding.port().detect_keypoints(img, 0)) > 2
+
+
+def test_cpp_shim_detect_and_describe(tmp_path):
+    """detectKeypointsAndDescriptors with the reference's argument list (keypoints.h:239-241)
+    over stand-in Pangolin/KeypointsData types; binary built by build()."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(cases.GOLDEN.rstrip("/")), "cpp", "shim_orb_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    xy, angles, desc = ex3_kd(1)
+    img = ex3_image(1)
+    np.ascontiguousarray(img).tofile(str(tmp_path / "img.bin"))
+    np.array([img.shape[1], img.shape[0]], np.int32).tofile(str(tmp_path / "dims.bin"))
+    xy.tofile(str(tmp_path / "corners.bin"))
+    angles.tofile(str(tmp_path / "angles.bin"))
+    desc.tofile(str(tmp_path / "desc.bin"))
+    r = subprocess.run([exe, str(tmp_path), "detect"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stdout + r.stderr

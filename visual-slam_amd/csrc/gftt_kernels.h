@@ -1,0 +1,126 @@
+// gftt_kernels.h -- gfx950 kernels of the corner detector.
+//
+// Path: visnav::detectKeypoints, /root/reference/include/visnav/keypoints.h:133-149 =
+// cv::goodFeaturesToTrack(image, points, num_features, 0.01, 8) + the EDGE_THRESHOLD filter.
+// OpenCV is a system dependency of the reference (absent here, no version pinned); the
+// per-pixel part of its published algorithm (3x3 Sobel -> covariance -> 3x3 box sums ->
+// minimum eigenvalue -> threshold at quality * max -> 3x3 local maxima) runs in these
+// kernels; the ordering of the candidates and the sequential minimum-distance pass stay on
+// the host (vsmatch.hip), as does the EDGE_THRESHOLD filter.
+//
+// Float arithmetic is kept exactly as the restatement in the checker does it: products and
+// sums in float with contraction off, the 3x3 box sums in double, correctly rounded sqrt.
+#pragma once
+#include "vsmatch_kernels.h"
+
+namespace vsm {
+
+__device__ __forceinline__ int reflect101(int p, int n) {  // BORDER_REFLECT_101, |offset| <= 1
+  if (n == 1) return 0;
+  return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p);
+}
+
+// Order-preserving map float -> u32 (for atomicMax over floats of either sign).
+__device__ __forceinline__ u32 float_key(float f) {
+  const u32 b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(u32 k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// grad[y * w + x] = (Dx, Dy): Sobel 3x3 scaled by 1 / (4 * 3 * 255) as cornerMinEigenVal
+// scales it for 8-bit input, block size 3, aperture 3.
+__global__ __launch_bounds__(256) void gftt_sobel_kernel(const uint8_t* __restrict__ img, int w, int h, u32 pitch,
+                                                         float2* __restrict__ grad) {
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = 2.0f * f1;
+  const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+  const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * pitch;
+  const uint8_t* r1 = img + (size_t)y * pitch;
+  const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * pitch;
+  const float a00 = r0[xm], a01 = r0[x], a02 = r0[xp];
+  const float a10 = r1[xm], a12 = r1[xp];
+  const float a20 = r2[xm], a21 = r2[x], a22 = r2[xp];
+  // Dx: row filter [-1 0 1] (exact), column filter [f1 f0 f1]
+  const float d0 = a02 - a00, d1 = a12 - a10, d2 = a22 - a20;
+  const float dxa = d1 * f0, dxb = (d0 + d2) * f1;
+  // Dy: row filter [f1 f0 f1], column filter [-1 0 1]
+  const float ta = a01 * f0, tb = (a00 + a02) * f1, ba = a21 * f0, bb = (a20 + a22) * f1;
+  const float top = ta + tb, bot = ba + bb;
+  grad[(size_t)y * w + x] = make_float2(dxa + dxb, bot - top);
+}
+
+// eig = minimum eigenvalue of the 3x3-summed covariance matrix (cv::cornerMinEigenVal);
+// *max_key = float_key(max eig) over the image (zero-initialised by the host).
+__global__ __launch_bounds__(256) void gftt_mineig_kernel(const float2* __restrict__ grad, int w, int h,
+                                                          float* __restrict__ eig, u32* __restrict__ max_key) {
+#pragma clang fp contract(off)
+  __shared__ u32 wave_max[4];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  u32 key = 0;
+  if (x < w && y < h) {
+    double cxx[3], cxy[3], cyy[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const float2* row = grad + (size_t)reflect101(y + j - 1, h) * w;
+      double rxx = 0, rxy = 0, ryy = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const float2 g = row[reflect101(x + i - 1, w)];
+        const float pxx = g.x * g.x, pxy = g.x * g.y, pyy = g.y * g.y;
+        rxx += (double)pxx;
+        rxy += (double)pxy;
+        ryy += (double)pyy;
+      }
+      cxx[j] = rxx;
+      cxy[j] = rxy;
+      cyy[j] = ryy;
+    }
+    const double sxx = (cxx[0] + cxx[1]) + cxx[2], sxy = (cxy[0] + cxy[1]) + cxy[2], syy = (cyy[0] + cyy[1]) + cyy[2];
+    const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+    const float amc = a - c;
+    const float t1 = amc * amc, t2 = b * b;
+    const float e = (a + c) - sqrtf(t1 + t2);
+    eig[(size_t)y * w + x] = e;
+    key = float_key(e);
+  }
+  for (int o = 32; o > 0; o >>= 1) key = max(key, (u32)__shfl_xor((int)key, o));
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 m = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (m) atomicMax(max_key, m);
+  }
+}
+
+// Candidates: interior pixels whose eigenvalue survives the threshold (float)(max * quality),
+// is non-zero and equals the 3x3 maximum of the thresholded map (cv::threshold TOZERO +
+// cv::dilate + the `val != 0 && val == tmp` test).  Appended unordered as
+// (float bits << 32 | pixel index); the host orders them.
+__global__ __launch_bounds__(256) void gftt_candidates_kernel(const float* __restrict__ eig, int w, int h,
+                                                              const u32* __restrict__ max_key, double quality,
+                                                              u64* __restrict__ cand, u32* __restrict__ count,
+                                                              u32 cap) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
+  const float thr = (float)((double)key_float(*max_key) * quality);
+  const float v = eig[(size_t)y * w + x];
+  if (!(v > thr) || v == 0.0f) return;
+  bool is_max = true;
+#pragma unroll
+  for (int j = -1; j <= 1; j++)
+#pragma unroll
+    for (int i = -1; i <= 1; i++) {
+      float u = eig[(size_t)(y + j) * w + (x + i)];
+      if (!(u > thr)) u = 0.0f;
+      is_max = is_max && !(u > v);
+    }
+  if (!is_max) return;
+  const u32 slot = atomicAdd(count, 1u);
+  if (slot < cap) cand[slot] = ((u64)__float_as_uint(v) << 32) | (u32)(y * w + x);
+}
+
+}  // namespace vsm

@@ -6,6 +6,7 @@
 #include "vsmatch_kernels.h"
 #include "landmark_kernels.h"
 #include "orb_kernels.h"
+#include "gftt_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -118,7 +119,8 @@ struct vsm_ctx {
   u32 max_n = 0;
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
-  PinBuf pin;
+  DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
+  PinBuf pin, pin_image;
   // measurement
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -454,9 +456,10 @@ void vsm_destroy(vsm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist,
-                      &c->w_pairs, &c->w_offsets, &c->w_out})
+                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt})
       b->release();
     c->pin.release();
+    c->pin_image.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -761,22 +764,35 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   return VSM_OK;
 }
 
-static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
-                    const double* corners_xy, size_t n, int rotate_features, const double* angles_in,
-                    double* angles_out, uint64_t* desc_out) {
-  VSM_TRY(check_ctx(c));
-  if (n == 0) return VSM_OK;
-  if (!img || !corners_xy) return fail(VSM_ERR_INVALID, "null image or corner pointer");
-  if (!angles_out && !desc_out) return fail(VSM_ERR_INVALID, "both outputs are null");
+static int check_image(const uint8_t* img, int width, int height, size_t pitch) {
+  if (!img) return fail(VSM_ERR_INVALID, "null image pointer");
   if (width <= 0 || height <= 0 || pitch < (size_t)width || width > 32768 || height > 32768)
     return fail(VSM_ERR_INVALID, "bad image geometry %d x %d, pitch %zu", width, height, pitch);
-  if (n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "more than VSM_MAX_SET corners");
+  return VSM_OK;
+}
+
+// Rows packed to `width` into the pinned image buffer, one async H2D into c->image.  The
+// pinned and device image buffers are used by nothing else, so later staging in the same
+// call cannot disturb the copy in flight.
+static int stage_image(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch) {
+  const size_t img_bytes = (size_t)width * height;
+  VSM_TRY(c->pin_image.reserve(img_bytes));
+  VSM_TRY(c->image.reserve(img_bytes));
+  char* h = (char*)c->pin_image.p;
+  if (pitch == (size_t)width) memcpy(h, img, img_bytes);
+  else
+    for (int y = 0; y < height; y++) memcpy(h + (size_t)y * width, img + (size_t)y * pitch, (size_t)width);
+  HIP_TRY(hipMemcpyAsync(c->image.p, h, img_bytes, hipMemcpyHostToDevice, c->stream));
+  return VSM_OK;
+}
+
+static int check_corners(const double* corners_xy, size_t n, int width, int height, bool need_border) {
   for (size_t i = 0; i < n; i++) {
     const double x = corners_xy[2 * i], y = corners_xy[2 * i + 1];
     // `const int cx = p[0]` (keypoints.h:158, 213) is undefined outside the int range
     if (!(std::fabs(x) < 1073741824.0) || !(std::fabs(y) < 1073741824.0))
       return fail(VSM_ERR_INVALID, "corner %zu is not finite or out of range", i);
-    if (desc_out) {
+    if (need_border) {
       // computeDescriptors reads up to 19 pixels away (keypoints.h:227-228); the reference only
       // ever passes corners that detectKeypoints kept (InBounds(.., EDGE_THRESHOLD), :145)
       const int cx = (int)x, cy = (int)y;
@@ -786,26 +802,27 @@ static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_
                     "the reference reads outside the image there", i, cx, cy, VSM_ORB_EDGE_THRESHOLD);
     }
   }
-  std::lock_guard<std::recursive_mutex> lk(c->mu);
-  DeviceGuard g(c->device);
-  // pinned staging: [image rows packed to `width` | corners | (cos, sin)] up,
-  //                 [moments | descriptors] down
+  return VSM_OK;
+}
+
+// computeAngles + computeDescriptors on the image already staged in c->image (mutex held,
+// device current, corners validated).
+static int orb_on_device(vsm_ctx* c, int width, int height, const double* corners_xy, size_t n,
+                         int rotate_features, const double* angles_in, double* angles_out, uint64_t* desc_out) {
+  // pinned staging: [corners | (cos, sin)] up, [moments | descriptors] down
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t img_bytes = (size_t)width * height;
-  const size_t o_img = 0, o_xy = al(img_bytes), o_cs = o_xy + al(n * 16), up_bytes = o_cs + al(n * 16);
+  const size_t o_xy = 0, o_cs = al(n * 16), up_bytes = o_cs + al(n * 16);
   const size_t o_mom = 0, o_desc = al(n * 8), down_bytes = o_desc + n * DESC_BYTES;
   VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
   VSM_TRY(c->stage.reserve(up_bytes));
   VSM_TRY(c->w_out.reserve(down_bytes));
   char* h = (char*)c->pin.p;
   char* hd = h + up_bytes;
-  if (pitch == (size_t)width) memcpy(h + o_img, img, img_bytes);
-  else
-    for (int y = 0; y < height; y++) memcpy(h + o_img + (size_t)y * width, img + (size_t)y * pitch, (size_t)width);
   memcpy(h + o_xy, corners_xy, n * 16);
   char* d = (char*)c->stage.p;
   char* dd = (char*)c->w_out.p;
-  HIP_TRY(hipMemcpyAsync(d, h, o_cs, hipMemcpyHostToDevice, c->stream));
+  const uint8_t* d_img = (const uint8_t*)c->image.p;
+  HIP_TRY(hipMemcpyAsync(d + o_xy, h + o_xy, n * 16, hipMemcpyHostToDevice, c->stream));
   double* cs = (double*)(h + o_cs);
   std::vector<double> ang_local;
   double* ang = angles_out;
@@ -816,9 +833,8 @@ static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_
   if (angles_in) {
     for (size_t i = 0; i < n; i++) ang[i] = angles_in[i];  // computeDescriptors: kd.corner_angles as given
   } else if (rotate_features) {
-    hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n + 3) / 4)), dim3(256), 0, c->stream,
-                       (const uint8_t*)(d + o_img), width, height, (u32)width, (const double2*)(d + o_xy),
-                       (u32)n, (int2*)(dd + o_mom));
+    hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n + 3) / 4)), dim3(256), 0, c->stream, d_img, width,
+                       height, (u32)width, (const double2*)(d + o_xy), (u32)n, (int2*)(dd + o_mom));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hd + o_mom, dd + o_mom, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -829,7 +845,7 @@ static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_
     for (size_t i = 0; i < n; i++) ang[i] = 0;  // keypoints.h:161
   }
   if (!desc_out) {
-    if (angles_in || !rotate_features) HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return VSM_OK;
   }
   for (size_t i = 0; i < n; i++) {  // keypoints.h:219, host libm
@@ -837,14 +853,171 @@ static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_
     cs[2 * i + 1] = std::sin(ang[i]);
   }
   HIP_TRY(hipMemcpyAsync(d + o_cs, h + o_cs, n * 16, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(orb_descriptor_kernel, dim3((u32)n), dim3(256), 0, c->stream,
-                     (const uint8_t*)(d + o_img), width, height, (u32)width, (const double2*)(d + o_xy),
-                     (const double2*)(d + o_cs), (u32)n, (u64*)(dd + o_desc));
+  hipLaunchKernelGGL(orb_descriptor_kernel, dim3((u32)n), dim3(256), 0, c->stream, d_img, width, height,
+                     (u32)width, (const double2*)(d + o_xy), (const double2*)(d + o_cs), (u32)n,
+                     (u64*)(dd + o_desc));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hd + o_desc, dd + o_desc, n * DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(desc_out, hd + o_desc, n * DESC_BYTES);
   return VSM_OK;
+}
+
+static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                    const double* corners_xy, size_t n, int rotate_features, const double* angles_in,
+                    double* angles_out, uint64_t* desc_out) {
+  VSM_TRY(check_ctx(c));
+  if (n == 0) return VSM_OK;
+  if (!corners_xy) return fail(VSM_ERR_INVALID, "null corner pointer");
+  if (!angles_out && !desc_out) return fail(VSM_ERR_INVALID, "both outputs are null");
+  VSM_TRY(check_image(img, width, height, pitch));
+  if (n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "more than VSM_MAX_SET corners");
+  VSM_TRY(check_corners(corners_xy, n, width, height, desc_out != nullptr));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  VSM_TRY(stage_image(c, img, width, height, pitch));
+  return orb_on_device(c, width, height, corners_xy, n, rotate_features, angles_in, angles_out, desc_out);
+}
+
+// cv::goodFeaturesToTrack on the image staged in c->image: per-pixel work on the device,
+// candidate ordering and the sequential minimum-distance pass on the host.
+static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, double quality,
+                          double min_distance, std::vector<double>& xy) {
+  xy.clear();
+  const size_t n = (size_t)width * height;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_grad = 0, o_eig = al(n * 8), o_cand = o_eig + al(n * 4), o_misc = o_cand + al(n * 8);
+  VSM_TRY(c->gftt.reserve(o_misc + 256));
+  char* d = (char*)c->gftt.p;
+  u32* d_misc = (u32*)(d + o_misc);  // [0] max key, [1] candidate count
+  HIP_TRY(hipMemsetAsync(d_misc, 0, 8, c->stream));
+  const dim3 grid((u32)((width + 63) / 64), (u32)((height + 3) / 4)), block(256);
+  hipLaunchKernelGGL(gftt_sobel_kernel, grid, block, 0, c->stream, (const uint8_t*)c->image.p, width, height,
+                     (u32)width, (float2*)(d + o_grad));
+  hipLaunchKernelGGL(gftt_mineig_kernel, grid, block, 0, c->stream, (const float2*)(d + o_grad), width, height,
+                     (float*)(d + o_eig), d_misc);
+  hipLaunchKernelGGL(gftt_candidates_kernel, grid, block, 0, c->stream, (const float*)(d + o_eig), width, height,
+                     (const u32*)d_misc, quality, (u64*)(d + o_cand), d_misc + 1, (u32)n);
+  HIP_TRY(hipGetLastError());
+  VSM_TRY(c->pin.reserve(256));
+  HIP_TRY(hipMemcpyAsync(c->pin.p, d_misc, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t nc = std::min<size_t>(((const u32*)c->pin.p)[1], n);
+  if (nc == 0) return VSM_OK;
+  VSM_TRY(c->pin.reserve(nc * 8));  // nothing is in flight here
+  HIP_TRY(hipMemcpyAsync(c->pin.p, d + o_cand, nc * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  u64* cand = (u64*)c->pin.p;
+  // value descending, ties by the higher pixel address first (cv greaterThanPtr)
+  std::sort(cand, cand + nc, [](u64 a, u64 b) {
+    float fa, fb;
+    const u32 ba = (u32)(a >> 32), bb = (u32)(b >> 32);
+    memcpy(&fa, &ba, 4);
+    memcpy(&fb, &bb, 4);
+    if (fa > fb) return true;
+    if (fa < fb) return false;
+    return (u32)a > (u32)b;
+  });
+  const u32 w = (u32)width;
+  if (min_distance >= 1) {
+    const int cell = (int)std::lrint(min_distance);  // cvRound
+    const int gw = (width + cell - 1) / cell, gh = (height + cell - 1) / cell;
+    std::vector<int> head((size_t)gw * gh, -1), next;
+    std::vector<u32> kept;
+    const double md2 = min_distance * min_distance;
+    for (size_t k = 0; k < nc; k++) {
+      const u32 idx = (u32)cand[k];
+      const int y = (int)(idx / w), x = (int)(idx % w);
+      const int xc = x / cell, yc = y / cell;
+      const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+      bool good = true;
+      for (int yy = y1; yy <= y2 && good; yy++)
+        for (int xx = x1; xx <= x2 && good; xx++)
+          for (int m = head[(size_t)yy * gw + xx]; m >= 0; m = next[m]) {
+            const float ddx = (float)x - (float)(kept[m] % w), ddy = (float)y - (float)(kept[m] / w);
+            if (ddx * ddx + ddy * ddy < md2) {
+              good = false;
+              break;
+            }
+          }
+      if (!good) continue;
+      next.push_back(head[(size_t)yc * gw + xc]);
+      head[(size_t)yc * gw + xc] = (int)kept.size();
+      kept.push_back(idx);
+      xy.push_back((double)x);
+      xy.push_back((double)y);
+      if (max_corners > 0 && (int)kept.size() == max_corners) break;
+    }
+  } else {
+    for (size_t k = 0; k < nc; k++) {
+      const u32 idx = (u32)cand[k];
+      xy.push_back((double)(idx % w));
+      xy.push_back((double)(idx / w));
+      if (max_corners > 0 && (int)(xy.size() / 2) == max_corners) break;
+    }
+  }
+  return VSM_OK;
+}
+
+// keypoints.h:144-148: keep the points with InBounds(x, y, EDGE_THRESHOLD)
+static void edge_filter(std::vector<double>& xy, int width, int height) {
+  size_t m = 0;
+  for (size_t i = 0; i + 1 < xy.size(); i += 2) {
+    const float x = (float)xy[i], y = (float)xy[i + 1], b = (float)VSM_ORB_EDGE_THRESHOLD;
+    if (b <= x && x < (float)width - b && b <= y && y < (float)height - b) {
+      xy[m++] = xy[i];
+      xy[m++] = xy[i + 1];
+    }
+  }
+  xy.resize(m);
+}
+
+static int detect_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch, int max_corners,
+                       double quality, double min_distance, bool edge, int describe, int rotate_features,
+                       double* corners_out, double* angles_out, uint64_t* desc_out, size_t cap, size_t* out_count) {
+  VSM_TRY(check_ctx(c));
+  if (!out_count) return fail(VSM_ERR_INVALID, "null out_count");
+  *out_count = 0;
+  VSM_TRY(check_image(img, width, height, pitch));
+  if (!(quality > 0) || !(min_distance >= 0) || max_corners < 0)  // the CV_Assert of cv::goodFeaturesToTrack
+    return fail(VSM_ERR_INVALID, "need qualityLevel > 0, minDistance >= 0, maxCorners >= 0");
+  if (cap && !corners_out) return fail(VSM_ERR_INVALID, "null corners_out with non-zero capacity");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  VSM_TRY(stage_image(c, img, width, height, pitch));
+  std::vector<double> xy;
+  VSM_TRY(gftt_on_device(c, width, height, max_corners, quality, min_distance, xy));
+  if (edge) edge_filter(xy, width, height);
+  const size_t n = xy.size() / 2;
+  *out_count = n;
+  if (n > cap) return fail(VSM_ERR_CAPACITY, "%zu corners need more than cap=%zu", n, cap);
+  if (n == 0) return VSM_OK;
+  memcpy(corners_out, xy.data(), n * 16);
+  if (!describe) return VSM_OK;
+  if (!angles_out || !desc_out) return fail(VSM_ERR_INVALID, "null angles_out or desc_out");
+  return orb_on_device(c, width, height, xy.data(), n, rotate_features, nullptr, angles_out, desc_out);
+}
+
+int vsm_good_features_to_track(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                               int max_corners, double quality_level, double min_distance,
+                               double* corners_out, size_t cap, size_t* out_count) {
+  return detect_impl(c, img, width, height, pitch, max_corners, quality_level, min_distance, false, 0, 0,
+                     corners_out, nullptr, nullptr, cap, out_count);
+}
+
+int vsm_detect_keypoints(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                         int num_features, double* corners_out, size_t cap, size_t* out_count) {
+  if (num_features < 0) return fail(VSM_ERR_INVALID, "num_features must be >= 0");
+  return detect_impl(c, img, width, height, pitch, num_features, 0.01, 8.0, true, 0, 0, corners_out, nullptr,
+                     nullptr, cap, out_count);
+}
+
+int vsm_detect_and_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,
+                            int num_features, int rotate_features, double* corners_out, double* angles_out,
+                            uint64_t* desc_out, size_t cap, size_t* out_count) {
+  if (num_features < 0) return fail(VSM_ERR_INVALID, "num_features must be >= 0");
+  return detect_impl(c, img, width, height, pitch, num_features, 0.01, 8.0, true, 1, rotate_features,
+                     corners_out, angles_out, desc_out, cap, out_count);
 }
 
 int vsm_orb_describe(vsm_ctx* c, const uint8_t* img, int width, int height, size_t pitch,

@@ -30,6 +30,7 @@ SYMBOLS = (
     "vsm_set_variant",
     "vsm_match_landmarks",
     "vsm_orb_describe", "vsm_orb_angles", "vsm_orb_descriptors",
+    "vsm_detect_keypoints", "vsm_good_features_to_track", "vsm_detect_and_describe",
 )
 
 
@@ -72,6 +73,11 @@ def lib():
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
             L.vsm_orb_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp, _vp]
+            L.vsm_detect_keypoints.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, _vp, _sz, C.POINTER(_sz)]
+            L.vsm_good_features_to_track.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, C.c_double, C.c_double,
+                                                     _vp, _sz, C.POINTER(_sz)]
+            L.vsm_detect_and_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, C.c_int, _vp, _vp, _vp,
+                                                  _sz, C.POINTER(_sz)]
             L.vsm_orb_angles.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp]
             L.vsm_orb_descriptors.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _vp, _sz, _vp]
             L.vsm_match_landmarks.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_double, C.c_int,
@@ -243,6 +249,58 @@ class Matcher:
                                       1 if rotate_features else 0, _ptr(ang),
                                       _ptr(desc) if descriptors else C.c_void_p(0)))
         return ang, desc
+
+    # -- keypoints.h:133-149, 239-245 ----------------------------------------------
+    @staticmethod
+    def _image(img):
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+            img = np.ascontiguousarray(img, dtype=np.uint8)
+            if img.ndim != 2:
+                raise ValueError("image must be 2-D uint8")
+        return img
+
+    def good_features_to_track(self, img, max_corners: int, quality_level: float = 0.01,
+                               min_distance: float = 8.0) -> np.ndarray:
+        """cv::goodFeaturesToTrack -> float64[n, 2] (x, y), strongest first."""
+        img = self._image(img)
+        h, w = img.shape
+        cap = max_corners if max_corners > 0 else w * h
+        n = _sz(0)
+        while True:
+            out = np.zeros((max(cap, 1), 2), dtype=np.float64)
+            rc = _check(lib().vsm_good_features_to_track(self._h, C.c_void_p(img.ctypes.data), w, h, img.strides[0],
+                                                         int(max_corners), float(quality_level), float(min_distance),
+                                                         _ptr(out), cap, C.byref(n)), allow=(VSM_ERR_CAPACITY,))
+            if rc == VSM_OK:
+                return out[: n.value].copy()
+            cap = n.value
+
+    def detect_keypoints(self, img, num_features: int) -> np.ndarray:
+        """visnav::detectKeypoints -> kd.corners float64[n, 2]."""
+        img = self._image(img)
+        h, w = img.shape
+        cap = num_features if num_features > 0 else w * h
+        out = np.zeros((max(cap, 1), 2), dtype=np.float64)
+        n = _sz(0)
+        _check(lib().vsm_detect_keypoints(self._h, C.c_void_p(img.ctypes.data), w, h, img.strides[0],
+                                          int(num_features), _ptr(out), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def detect_and_describe(self, img, num_features: int, rotate_features: bool = True):
+        """visnav::detectKeypointsAndDescriptors -> (corners f64[n,2], angles f64[n], descriptors u64[n,4])."""
+        img = self._image(img)
+        h, w = img.shape
+        cap = max(num_features if num_features > 0 else w * h, 1)
+        xy = np.zeros((cap, 2), dtype=np.float64)
+        ang = np.zeros(cap, dtype=np.float64)
+        desc = np.zeros((cap, 4), dtype=np.uint64)
+        n = _sz(0)
+        _check(lib().vsm_detect_and_describe(self._h, C.c_void_p(img.ctypes.data), w, h, img.strides[0],
+                                             int(num_features), 1 if rotate_features else 0, _ptr(xy), _ptr(ang),
+                                             _ptr(desc), cap, C.byref(n)))
+        k = n.value
+        return xy[:k].copy(), ang[:k].copy(), desc[:k].copy()
 
     def orb_descriptors(self, img, corners_xy, angles) -> np.ndarray:
         """visnav::computeDescriptors with caller-given angles (keypoints.h:203-237)."""
