@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void gftt_mineig_kernel(const float2* __restri
 // Candidates: interior pixels whose eigenvalue survives the threshold (float)(max * quality),
 // is non-zero and equals the 3x3 maximum of the thresholded map (cv::threshold TOZERO +
 // cv::dilate + the `val != 0 && val == tmp` test).  Appended unordered as
-// (float bits << 32 | pixel index); the host orders them.
+// (float_key(value) << 32 | pixel index), a key whose unsigned DEScending order is OpenCV's
+// candidate order: value descending, ties by the higher pixel address first (greaterThanPtr).
 __global__ __launch_bounds__(256) void gftt_candidates_kernel(const float* __restrict__ eig, int w, int h,
                                                               const u32* __restrict__ max_key, double quality,
                                                               u64* __restrict__ cand, u32* __restrict__ count,
@@ -120,7 +121,32 @@ __global__ __launch_bounds__(256) void gftt_candidates_kernel(const float* __res
     }
   if (!is_max) return;
   const u32 slot = atomicAdd(count, 1u);
-  if (slot < cap) cand[slot] = ((u64)__float_as_uint(v) << 32) | (u32)(y * w + x);
+  if (slot < cap) cand[slot] = ((u64)float_key(v) << 32) | (u32)(y * w + x);
+}
+
+// Orders the candidates by brute force, the way the matcher scans descriptors: thread i
+// counts the keys greater than its own (tiles of 256 keys through LDS, broadcast reads) and
+// that count is its position -- keys are unique (they carry the pixel index), so this is a
+// permutation.  n^2 / 2^14 lane-iterations: 15 k candidates take ~25 us, against ~1 ms for a
+// host sort; the host falls back to std::sort above GFTT_RANK_SORT_MAX.
+constexpr u32 GFTT_RANK_SORT_MAX = 65536;
+__global__ __launch_bounds__(256) void gftt_rank_sort_kernel(const u64* __restrict__ cand,
+                                                             const u32* __restrict__ count, u32 cap,
+                                                             u64* __restrict__ sorted) {
+  __shared__ u64 tile[256];
+  const u32 n = min(*count, cap);
+  if (n > GFTT_RANK_SORT_MAX || blockIdx.x * 256 >= n) return;  // block-uniform
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  const u64 mine = i < n ? cand[i] : 0;
+  u32 rank = 0;
+  for (u32 base = 0; base < n; base += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = base + threadIdx.x < n ? cand[base + threadIdx.x] : 0;  // 0 is below every real key
+    __syncthreads();
+#pragma unroll 8
+    for (u32 j = 0; j < 256; j++) rank += tile[j] > mine ? 1u : 0u;
+  }
+  if (i < n) sorted[rank] = mine;
 }
 
 }  // namespace vsm

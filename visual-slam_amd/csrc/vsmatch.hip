@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -886,6 +887,7 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
   xy.clear();
   const size_t n = (size_t)width * height;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // device work area: gradients (later reused for the ordered candidates) | eig | candidates | misc
   const size_t o_grad = 0, o_eig = al(n * 8), o_cand = o_eig + al(n * 4), o_misc = o_cand + al(n * 8);
   VSM_TRY(c->gftt.reserve(o_misc + 256));
   char* d = (char*)c->gftt.p;
@@ -898,26 +900,31 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
                      (float*)(d + o_eig), d_misc);
   hipLaunchKernelGGL(gftt_candidates_kernel, grid, block, 0, c->stream, (const float*)(d + o_eig), width, height,
                      (const u32*)d_misc, quality, (u64*)(d + o_cand), d_misc + 1, (u32)n);
+  // order them on the device (the gradient area is free again); sized for the largest count the
+  // kernel sorts -- it reads the real count itself, so no host round trip is needed in between
+  const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + 255) / 256);
+  hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, (const u64*)(d + o_cand),
+                     (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad));
   HIP_TRY(hipGetLastError());
-  VSM_TRY(c->pin.reserve(256));
-  HIP_TRY(hipMemcpyAsync(c->pin.p, d_misc, 8, hipMemcpyDeviceToHost, c->stream));
+  // one speculative download: the count and the first GFTT_FIRST_COPY ordered candidates
+  constexpr size_t GFTT_FIRST_COPY = 4096;
+  VSM_TRY(c->pin.reserve(256 + std::max<size_t>(GFTT_FIRST_COPY, 1) * 8));
+  char* hp = (char*)c->pin.p;
+  HIP_TRY(hipMemcpyAsync(hp, d_misc, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(hp + 256, d + o_grad, std::min(n, GFTT_FIRST_COPY) * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  const size_t nc = std::min<size_t>(((const u32*)c->pin.p)[1], n);
+  const size_t nc = std::min<size_t>(((const u32*)hp)[1], n);
   if (nc == 0) return VSM_OK;
-  VSM_TRY(c->pin.reserve(nc * 8));  // nothing is in flight here
-  HIP_TRY(hipMemcpyAsync(c->pin.p, d + o_cand, nc * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  u64* cand = (u64*)c->pin.p;
-  // value descending, ties by the higher pixel address first (cv greaterThanPtr)
-  std::sort(cand, cand + nc, [](u64 a, u64 b) {
-    float fa, fb;
-    const u32 ba = (u32)(a >> 32), bb = (u32)(b >> 32);
-    memcpy(&fa, &ba, 4);
-    memcpy(&fb, &bb, 4);
-    if (fa > fb) return true;
-    if (fa < fb) return false;
-    return (u32)a > (u32)b;
-  });
+  const bool device_sorted = nc <= GFTT_RANK_SORT_MAX;
+  if (nc > GFTT_FIRST_COPY || !device_sorted) {
+    VSM_TRY(c->pin.reserve(256 + nc * 8));  // nothing is in flight here
+    hp = (char*)c->pin.p;
+    HIP_TRY(hipMemcpyAsync(hp + 256, d + (device_sorted ? o_grad : o_cand), nc * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  u64* cand = (u64*)(hp + 256);
+  // value descending, ties by the higher pixel address first (cv greaterThanPtr) = key descending
+  if (!device_sorted) std::sort(cand, cand + nc, std::greater<u64>());
   const u32 w = (u32)width;
   if (min_distance >= 1) {
     const int cell = (int)std::lrint(min_distance);  // cvRound
