@@ -84,7 +84,8 @@ def main():
         json.dump({"images": images, "pairs": pairs, "images_verified_against_reference_map_file": len(ref_map),
                    "euroc_V1_full_set": {"images": len(files), "corners_min": int(min(sizes)),
                                          "corners_mean": float(np.mean(sizes)), "corners_max": int(max(sizes)),
-                                         "non_stereo_pairs": len(files) * (len(files) - 1) // 2 - len(stamps)}},
+                                         "non_stereo_pairs": len(files) * (len(files) - 1) // 2 - len(stamps),
+                                         "corners_per_image": [int(v) for v in sizes]}},
                   f, indent=1)
     print(json.dumps(images, indent=1)[:400], "\n", len(pairs), "pairs", sum(p["matches"] for p in pairs), "matches")
 

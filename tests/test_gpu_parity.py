@@ -47,10 +47,12 @@ def test_pair_matches_recorded_reference(m, name):
     assert np.array_equal(got, binding.port().match(d1, d2, thr, ratio))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
+                                     0x40008, 0x60008, 0x40308])
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
-    tracking [bit 17], with forced train splits [bits 8-15]) gives the same list."""
+    tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
+    decomposition unless bit 18 is set) gives the same list."""
     m.set_variant(variant)
     try:
         for name in ("ex3_thr70_r1.2", "planted_300x777", "planted_1023x1025", "planted_4100x130",
@@ -222,3 +224,29 @@ def test_nn2_large_sampled_against_oracle(m):
     pick = rng.choice(n, size=48, replace=False)
     wi, wd, ws = binding.port().nn2(q[pick], t)
     assert np.array_equal(bi[pick], wi) and np.array_equal(bd[pick], wd) and np.array_equal(sd[pick], ws)
+
+
+def test_adaptive_tiles_on_ragged_database(m):
+    """scan_kernel_adaptive: image sizes on and around every tile boundary (multiples of 64 up to
+    1025, so every 256/128/64 remainder combination occurs, forward and in the pruned backward
+    pass), all pairs as one batch large enough for the R = 8 regime, against the oracle; the
+    fixed-tile kernels (variant bit 18) must give the same lists."""
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448,
+             449, 511, 512, 513, 575, 576, 577, 640, 704, 768, 832, 896, 959, 960, 961, 1023, 1024, 1025]
+    db, off = cases.synth.sfm_database(len(sizes), sizes, seed=77, share_frac=0.5, window=40)
+    pairs = cases.synth.all_pairs(len(sizes))
+    pairs = np.concatenate([pairs, pairs[:, ::-1]])  # both orientations
+    m.db_upload(db, off)
+    offs, lists = m.match_pairs(pairs, 70, 1.2)
+    m.set_variant(0x40000)
+    try:
+        offs_fixed, lists_fixed = m.match_pairs(pairs, 70, 1.2)
+    finally:
+        m.set_variant(0)
+    assert np.array_equal(offs, offs_fixed) and np.array_equal(lists, lists_fixed)
+    assert len(lists) > 20000
+    o = binding.port()
+    for k in range(0, len(pairs), 7):
+        i, j = pairs[k]
+        want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want), (k, i, j)

@@ -118,6 +118,7 @@ struct vsm_ctx {
   DevBuf d_img_off;
   std::vector<u32> img_off;
   u32 max_n = 0;
+  u32 max_tiles = 0;  // most adaptive tiles any image of the database needs
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
@@ -218,13 +219,23 @@ int stats_collect(vsm_ctx* c) {
 struct ScanShape {
   int R;
   u32 wgs_per_job, splits;
-  bool fkey;  // float-key tracking (scan range per split <= FKEY_MAX_SET)
+  bool fkey;      // float-key tracking (scan range per split <= FKEY_MAX_SET)
+  bool adaptive;  // scan_kernel_adaptive: 512-query tiles + 256/128/64 remainder tiles (R == 8 only)
 };
+
+// Most tiles scan_kernel_adaptive can need for a job of at most max_nq queries (the tile
+// count is not monotone in nq: 448 queries are 3 tiles, 512 are 1).
+u32 adaptive_tiles_bound(u32 max_nq) {
+  const u32 n64 = (max_nq + 63) >> 6;
+  u32 best = 0;
+  for (u32 k = n64 > 16 ? n64 - 16 : 0; k <= n64; k++) best = std::max(best, adaptive_tiles(k * 64));
+  return best;
+}
 
 // Queries per wave (64*R) and train splits.  Large batches: R = 4, no split.
 // Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
 // query per lane and the train range split over grid.y so that all 256 CUs work.
-ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
+ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exact_max_tiles = 0) {
   ScanShape s;
   // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
   // override, bit 17 = integer-key tracking everywhere
@@ -237,7 +248,10 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant) {
   s.R = waves_r8 >= TARGET_WAVES ? 8 : waves_r4 >= TARGET_WAVES ? 4 : 1;
   if (vr == 1 || vr == 2 || vr == 4 || vr == 8) s.R = vr;
   const u32 tq = 64 * s.R;
-  const u32 tiles = (max_nq + tq - 1) / tq;
+  // bit 18 of the experiment knob: fixed 512-query tiles instead of the adaptive decomposition
+  s.adaptive = s.R == 8 && !(variant & 0x40000);
+  const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles : adaptive_tiles_bound(max_nq))
+                               : (max_nq + tq - 1) / tq;
   s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
   const u64 waves = std::max<u64>(1, n_jobs * tiles);
   // (a) latency regime: reach TARGET_WAVES with at least 64 train items per split;
@@ -276,6 +290,14 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
                      sh.splits, split_stride, d_scratch, d_qlist)
   // FILL 5 = float-key tracking (train range per split <= 32768), FILL 2 = integer keys
   // with a v_mov filler behind every v_bcnt; both measured in profiles/r01/scan_variants.txt
+  if (sh.adaptive) {
+    if (sh.fkey)
+      hipLaunchKernelGGL((scan_kernel_adaptive<5>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
+                         split_stride, d_scratch, d_qlist);
+    else
+      hipLaunchKernelGGL((scan_kernel_adaptive<2>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
+                         split_stride, d_scratch, d_qlist);
+  } else
   switch (sh.R * 2 + (sh.fkey ? 1 : 0)) {
     case 2: VSM_LAUNCH(1, 2); break;
     case 3: VSM_LAUNCH(1, 5); break;
@@ -317,7 +339,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     return VSM_OK;
   }
   const u32 stride = std::max(64u, round_up(max_n, 64));
-  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant);
+  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : 0);
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
@@ -332,11 +354,15 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   // fit the LDS bitmap; bit 16 of the experiment knob turns it off for A/B runs.
   const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & 0x10000);
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
-  ScanShape shb = sh;  // backward jobs of the pruned pass: one query per lane, ragged lists
-  shb.R = 1;
-  shb.fkey = sh.fkey;
+  // Backward jobs of the pruned pass scan ragged nominated lists whose lengths only the device
+  // knows: one query per lane, fixed 64-query tiles.  (Adaptive tiles were measured here and
+  // lose: a sparse batch has one live wave per job, and the 114-VGPR adaptive kernel holds
+  // half as many of them per SIMD as the 33-VGPR R = 1 kernel -- 0.45 -> 1.18 ms per launch;
+  // a dense batch gets too few, too long waves -- 4.4 -> 5.4 ms.)
+  ScanShape shb = sh;
+  shb.adaptive = false;
   const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
-  if (vbr == 1 || vbr == 2 || vbr == 4 || vbr == 8) shb.R = vbr;
+  shb.R = (vbr == 1 || vbr == 2 || vbr == 4 || vbr == 8) ? vbr : 1;
   shb.wgs_per_job = std::max(1u, ((max_n + 64 * shb.R - 1) / (64 * shb.R) + 3) / 4);
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
@@ -399,10 +425,11 @@ int check_ctx(vsm_ctx* c) {
 int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
   if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
   if (n_img >= 0xffffffffull) return fail(VSM_ERR_INVALID, "too many images");
-  u32 max_n = 0;
+  u32 max_n = 0, max_tiles = 0;
   for (size_t i = 0; i < n_img; i++) {
     if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
     max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
+    max_tiles = std::max(max_tiles, adaptive_tiles(offsets[i + 1] - offsets[i]));
   }
   if (max_n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "image with %u descriptors exceeds VSM_MAX_SET", max_n);
   if (n_img && !d_desc && offsets[n_img] != 0) return fail(VSM_ERR_INVALID, "null descriptor pointer");
@@ -411,6 +438,7 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->img_off.assign(offsets, offsets + n_img + 1);
   c->max_n = max_n;
+  c->max_tiles = max_tiles;
   c->db = d_desc;
   return VSM_OK;
 }

@@ -173,23 +173,13 @@ typedef const __attribute__((address_space(4))) u32x8 cdesc_t;
 // queries q0 + r*64 + l, so every query load is a coalesced 2 KiB) and scans
 // its split of the train range.  Waves never communicate; there is no LDS and
 // no barrier in this kernel.
-template <int R, int FILL = 0>
-__global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qbase,
-                                                   const u32x4* __restrict__ tbase,
-                                                   const Job* __restrict__ jobs, u32 n_jobs,
-                                                   u32 splits, u32 split_stride,
-                                                   uint2* __restrict__ scratch,
-                                                   const u32* __restrict__ qlist) {
-  constexpr u32 TQ = 64 * R;
-  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const u32 lane = threadIdx.x & 63;
-  const u32 wg_of_job = blockIdx.x / n_jobs;
-  const u32 job_id = blockIdx.x - wg_of_job * n_jobs;
-  const u32 tile = wg_of_job * 4 + wave;
-  const u32 split = blockIdx.y;
-  const Job job = jobs[job_id];
-  const u32 q0 = tile * TQ;
-  if (q0 >= job.nq) return;
+// One tile = 64*R queries of a job (lane l holds queries q0 + r*64 + l) against the split's
+// share of the job's train range.
+template <int R, int FILL>
+__device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
+                                          const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
+                                          u32 split_stride, uint2* __restrict__ scratch,
+                                          const u32* __restrict__ qlist) {
   const u32 per = (job.nt + splits - 1) / splits;
   const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
 
@@ -238,6 +228,72 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
     }
     if (qi < job.nq) out[col[r]] = make_uint2(best[r], second[r]);
   }
+}
+
+template <int R, int FILL = 0>
+__global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qbase,
+                                                   const u32x4* __restrict__ tbase,
+                                                   const Job* __restrict__ jobs, u32 n_jobs,
+                                                   u32 splits, u32 split_stride,
+                                                   uint2* __restrict__ scratch,
+                                                   const u32* __restrict__ qlist) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 wg_of_job = blockIdx.x / n_jobs;
+  const u32 job_id = blockIdx.x - wg_of_job * n_jobs;
+  const Job job = jobs[job_id];
+  const u32 q0 = (wg_of_job * 4 + wave) * 64 * R;
+  if (q0 >= job.nq) return;
+  scan_tile<R, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
+}
+
+// Ragged jobs (real images have 100..1400 corners, not a multiple of 512): the job's queries are
+// cut into tiles of 512 (R = 8) and, for the remainder, one tile per set bit of
+// ceil(rest / 64) -- 256, 128, 64 queries (R = 4, 2, 1) -- so that a wave never carries more than
+// 63 idle query slots.  Same grid as scan_kernel; the wave index within the job selects the
+// tile.  adaptive_tiles(nq) on the host gives the number of tiles a job of nq queries has.
+__host__ __device__ inline u32 adaptive_tiles(u32 nq) {
+  const u32 n64 = (nq + 63) >> 6, rem = n64 & 7;
+  return (n64 >> 3) + ((rem >> 2) & 1) + ((rem >> 1) & 1) + (rem & 1);
+}
+template <int FILL>
+__global__ __launch_bounds__(256) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
+                                                            const u32x4* __restrict__ tbase,
+                                                            const Job* __restrict__ jobs, u32 n_jobs,
+                                                            u32 splits, u32 split_stride,
+                                                            uint2* __restrict__ scratch,
+                                                            const u32* __restrict__ qlist) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  const u32 wg_of_job = blockIdx.x / n_jobs;
+  const u32 job_id = blockIdx.x - wg_of_job * n_jobs;
+  const Job job = jobs[job_id];
+  const u32 t = wg_of_job * 4 + wave;
+  const u32 n64 = (job.nq + 63) >> 6, full = n64 >> 3, rem = n64 & 7;
+  if (t < full) {
+    scan_tile<8, FILL>(qbase, tbase, job, t * 512, lane, blockIdx.y, splits, split_stride, scratch, qlist);
+    return;
+  }
+  // remainder tiles in the order 256, 128, 64 (those whose bit is set in rem)
+  u32 k = t - full, q0 = full * 512;
+  if (rem & 4) {
+    if (k == 0) {
+      scan_tile<4, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
+      return;
+    }
+    k--;
+    q0 += 256;
+  }
+  if (rem & 2) {
+    if (k == 0) {
+      scan_tile<2, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
+      return;
+    }
+    k--;
+    q0 += 128;
+  }
+  if ((rem & 1) && k == 0)
+    scan_tile<1, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
 }
 
 // Exact merge of two partial (best key, second key) results over disjoint
