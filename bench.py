@@ -262,7 +262,7 @@ def main():
     assert 0 < scan_comps <= comps_rank, (scan_comps, comps_rank)
     achieved = fwd["comparisons"] * LANE_OPS_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
     roofline = {
-        "bound": "valu", "kernel": "scan_kernel<8,5> (forward scans, the dominant kernel)",
+        "bound": "valu", "kernel": "scan_kernel_adaptive<7> (forward scans, the dominant kernel: 512-query tiles, float keys)",
         "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlaneop/s", "frac": achieved / PEAK_TLANEOPS,
         "frac_of_nominal_64_lanes_per_clk_peak": achieved / NOMINAL_TLANEOPS,
         "traffic": None,
@@ -272,7 +272,7 @@ def main():
                        "peak = 1024 SIMDs x 64 lanes x 2.4 GHz / (8 x 2.32 + 8 x 4.61 measured issue cycles) "
                        "x 16 = 45.4 T lane-ops/s; nominal BASELINE.md peak (64 lanes/clk/CU) = 39.32 T",
         "kernel_gcomps": fwd["comparisons"] / (fwd["scan_ms"] * 1e-3) / 1e9,
-        "backward_pruned": {"kernel": "scan_kernel<1,5>", "launches": bwd["launches"],
+        "backward_pruned": {"kernel": "scan_kernel<1,7>", "launches": bwd["launches"],
                             "avg_launch_ms": bwd["scan_ms"] / max(1, bwd["launches"]),
                             "kernel_gcomps": (bwd["comparisons"] / (bwd["scan_ms"] * 1e-3) / 1e9) if bwd["scan_ms"] else None},
         "evaluated_over_reference_equivalent": scan_comps / comps_rank,

@@ -48,11 +48,12 @@ def test_pair_matches_recorded_reference(m, name):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
-                                     0x40008, 0x60008, 0x40308])
+                                     0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008])
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
     tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
-    decomposition unless bit 18 is set) gives the same list."""
+    decomposition unless bit 18 is set; bit 19 selects the plain float-key sequence FILL 5
+    instead of FILL 7) gives the same list."""
     m.set_variant(variant)
     try:
         for name in ("ex3_thr70_r1.2", "planted_300x777", "planted_1023x1025", "planted_4100x130",

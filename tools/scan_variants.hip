@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256) void scan_kernel_lds(const u32x4* __restrict__
   u32 best[R], second[R];
 #pragma unroll
   for (int r = 0; r < R; r++) best[r] = second[r] = (FILL == 5 ? FKEY_INIT : KEY_INIT);
+  Pend pend = {PEND_INIT_D, FKEY_MAGIC};
   const u32x4* tr = tbase + 2 * (size_t)job.t_off;
   const u32 n_vec = 2 * job.nt;  // u32x4 units in the train range
   const u32 stages = (job.nt + TT - 1) / TT;
@@ -89,13 +90,13 @@ __global__ __launch_bounds__(256) void scan_kernel_lds(const u32x4* __restrict__
       const u32x4 b0 = tile[buf][2 * j + 2], b1 = tile[buf][2 * j + 3];
       const u32x8 ta = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
       const u32x8 tb = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      update<R, FILL>(q, ta, base + j, best, second);
-      update<R, FILL>(q, tb, base + j + 1, best, second);
+      update<R, FILL>(q, ta, base + j, best, second, pend);
+      update<R, FILL>(q, tb, base + j + 1, best, second, pend);
     }
     for (; j < cnt; j++) {
       const u32x4 a0 = tile[buf][2 * j], a1 = tile[buf][2 * j + 1];
       const u32x8 ta = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      update<R, FILL>(q, ta, base + j, best, second);
+      update<R, FILL>(q, ta, base + j, best, second, pend);
     }
     if (s + 1 < stages) {
 #pragma unroll
@@ -150,6 +151,8 @@ int main(int argc, char** argv) {
       {"LDS R8 f32 key TT128", scan_kernel_lds<8, 5, 128>, 8}, {"LDS R8 f32 key TT256", scan_kernel_lds<8, 5, 256>, 8},
       {"LDS R4 f32 key TT128", scan_kernel_lds<4, 5, 128>, 4}, {"LDS R8 int key TT128", scan_kernel_lds<8, 2, 128>, 8},
       {"LDS R8 int nofill TT128", scan_kernel_lds<8, 0, 128>, 8},
+      {"R8 fill7 add,fma pb", scan_kernel<8, 7>, 8}, {"R4 fill7 add,fma pb", scan_kernel<4, 7>, 4},
+      {"R2 fill7 add,fma pb", scan_kernel<2, 7>, 2}, {"R1 fill7 add,fma pb", scan_kernel<1, 7>, 1},
       {"R2 fill5 f32 key", scan_kernel<2, 5>, 2}, {"R1 fill5 f32 key", scan_kernel<1, 5>, 1}, {"R1 fill2", scan_kernel<1, 2>, 1},
   };
   hipEvent_t e0, e1;

@@ -288,25 +288,35 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #define VSM_LAUNCH(RR, FF)                                                                          \
   hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
                      sh.splits, split_stride, d_scratch, d_qlist)
-  // FILL 5 = float-key tracking (train range per split <= 32768), FILL 2 = integer keys
-  // with a v_mov filler behind every v_bcnt; both measured in profiles/r01/scan_variants.txt
+  // Float-key tracking (train range per split <= 32768): FILL 7 (key construction in the next
+  // chain's filler slots; FILL 5, the plain float-key sequence, with bit 19 of the experiment
+  // knob); integer keys with a v_mov filler behind every v_bcnt otherwise (FILL 2).  All
+  // measured in profiles/r01/scan_variants*.txt.
+  const int fill = !sh.fkey ? 2 : (c->variant & 0x80000) ? 5 : 7;
   if (sh.adaptive) {
-    if (sh.fkey)
+    if (fill == 7)
+      hipLaunchKernelGGL((scan_kernel_adaptive<7>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
+                         split_stride, d_scratch, d_qlist);
+    else if (fill == 5)
       hipLaunchKernelGGL((scan_kernel_adaptive<5>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
                          split_stride, d_scratch, d_qlist);
     else
       hipLaunchKernelGGL((scan_kernel_adaptive<2>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
                          split_stride, d_scratch, d_qlist);
   } else
-  switch (sh.R * 2 + (sh.fkey ? 1 : 0)) {
-    case 2: VSM_LAUNCH(1, 2); break;
-    case 3: VSM_LAUNCH(1, 5); break;
-    case 4: VSM_LAUNCH(2, 2); break;
-    case 5: VSM_LAUNCH(2, 5); break;
-    case 8: VSM_LAUNCH(4, 2); break;
-    case 9: VSM_LAUNCH(4, 5); break;
-    case 16: VSM_LAUNCH(8, 2); break;
-    case 17: VSM_LAUNCH(8, 5); break;
+  switch (sh.R * 16 + fill) {
+    case 16 + 2: VSM_LAUNCH(1, 2); break;
+    case 16 + 5: VSM_LAUNCH(1, 5); break;
+    case 16 + 7: VSM_LAUNCH(1, 7); break;
+    case 32 + 2: VSM_LAUNCH(2, 2); break;
+    case 32 + 5: VSM_LAUNCH(2, 5); break;
+    case 32 + 7: VSM_LAUNCH(2, 7); break;
+    case 64 + 2: VSM_LAUNCH(4, 2); break;
+    case 64 + 5: VSM_LAUNCH(4, 5); break;
+    case 64 + 7: VSM_LAUNCH(4, 7); break;
+    case 128 + 2: VSM_LAUNCH(8, 2); break;
+    case 128 + 5: VSM_LAUNCH(8, 5); break;
+    case 128 + 7: VSM_LAUNCH(8, 7); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
   }
 #undef VSM_LAUNCH

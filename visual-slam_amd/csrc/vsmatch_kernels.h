@@ -106,9 +106,49 @@ __device__ __forceinline__ u32 fkey_to_key(u32 fbits, u32 base) {
   return d >= 256u ? KEY_INIT : ((d << IDX_BITS) | ((k & 32767u) + base));
 }
 
+// FILL == 7: float keys as in 5, with the key construction of a comparison riding in the filler
+// slots of the NEXT comparison's popcount chain: v_add_f32 and v_fma_f32 sit behind its first
+// two v_bcnt (where FILL 5 has a v_mov), v_med3_f32 + v_min_f32 follow (the min is the med3's
+// filler), v_mov behind the other six v_bcnt: 26 issued instructions per comparison instead of
+// 27.  Measured (tools/scan_variants, profiles/r01/scan_variants_piggyback.txt): R = 8 +1.6 %,
+// R = 4 +5 % over FILL 5.  v_min_f32 / v_max_f32 / v_med3_f32 do NOT work as fillers (moving
+// them into filler slots too, 24-25 instructions, is slower), only add/mul/fma f32 and v_mov do.
+// `Pend` carries the last chain of one call (its popcount result and the bit pattern of
+// 2^23 + j) into the next call; scan_tile flushes it after the last train descriptor.
+struct Pend {
+  u32 d, jf;
+};
+constexpr u32 PEND_INIT_D = FKEY_MAGIC + 256u;  // distance 256: a key >= FKEY_INIT, never recorded
+
 template <int R, int FILL>
 __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 j, u32 (&best)[R],
-                                       u32 (&second)[R]) {
+                                       u32 (&second)[R], Pend& pend) {
+  if (FILL == 7) {
+    const u32 magic = FKEY_MAGIC;
+    const float scale = 32768.0f;
+    const u32 jf = FKEY_MAGIC + j;
+    u32 dprev = pend.d;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int pr = (r + R - 1) % R;             // the comparison whose tracking rides along
+      const u32 jfp = r == 0 ? pend.jf : jf;      // ... and the train index it was made with
+      u32 d, df, key, nb, ns;
+      asm("v_bcnt_u32_b32 %0, %2, %3\n\tv_add_f32 %1, 0xcb000000, %4"
+          : "=&v"(d), "=v"(df) : "v"(q[r][0] ^ t[0]), "v"(magic), "v"(dprev));
+      asm("v_bcnt_u32_b32 %0, %2, %0\n\tv_fma_f32 %1, %3, %4, %5"
+          : "+v"(d), "=v"(key) : "v"(q[r][1] ^ t[1]), "v"(df), "v"(scale), "s"(jfp));
+      asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
+          : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
+      best[pr] = nb;
+      second[pr] = ns;
+#pragma unroll
+      for (int w = 2; w < 8; w++) d = bcnt_acc<2>(q[r][w] ^ t[w], d);
+      dprev = d;
+    }
+    pend.d = dprev;
+    pend.jf = jf;
+    return;
+  }
   if (FILL == 5) {
     const u32 magic = FKEY_MAGIC;
     const float scale = 32768.0f;
@@ -195,12 +235,13 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
   }
   u32 best[R], second[R];
 #pragma unroll
-  for (int r = 0; r < R; r++) best[r] = second[r] = (FILL == 5 ? FKEY_INIT : KEY_INIT);
+  for (int r = 0; r < R; r++) best[r] = second[r] = (FILL >= 5 ? FKEY_INIT : KEY_INIT);
+  Pend pend = {PEND_INIT_D, FKEY_MAGIC};
 
   if (t1 > t0) {
     cdesc_t* tr = (cdesc_t*)(uintptr_t)tbase + job.t_off;
     const u32 last = t1 - 1;
-    const u32 jb = FILL == 5 ? t0 : 0u;  // float keys count from the start of the range
+    const u32 jb = FILL >= 5 ? t0 : 0u;  // float keys count from the start of the range
     u32 j = t0;
     // Software-pipelined: two groups of two descriptors in SGPRs; the loads of
     // one group are in flight while the other is consumed.  Indices past the
@@ -208,21 +249,27 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
     u32x8 a0 = tr[min(j, last)], a1 = tr[min(j + 1, last)];
     for (; j + 4 <= t1; j += 4) {
       const u32x8 b0 = tr[j + 2], b1 = tr[j + 3];
-      update<R, FILL>(q, a0, j - jb, best, second);
-      update<R, FILL>(q, a1, j + 1 - jb, best, second);
+      update<R, FILL>(q, a0, j - jb, best, second, pend);
+      update<R, FILL>(q, a1, j + 1 - jb, best, second, pend);
       a0 = tr[min(j + 4, last)];
       a1 = tr[min(j + 5, last)];
-      update<R, FILL>(q, b0, j + 2 - jb, best, second);
-      update<R, FILL>(q, b1, j + 3 - jb, best, second);
+      update<R, FILL>(q, b0, j + 2 - jb, best, second, pend);
+      update<R, FILL>(q, b1, j + 3 - jb, best, second, pend);
     }
-    for (; j < t1; ++j) update<R, FILL>(q, tr[j], j - jb, best, second);
+    for (; j < t1; ++j) update<R, FILL>(q, tr[j], j - jb, best, second, pend);
   }
 
+  if (FILL == 7) {  // the last chain's tracking is still pending
+    const float key = fmaf(__uint_as_float(pend.d) - 8388608.0f, 32768.0f, __uint_as_float(pend.jf));
+    const float b = __uint_as_float(best[R - 1]), sc = __uint_as_float(second[R - 1]);
+    second[R - 1] = __float_as_uint(__builtin_amdgcn_fmed3f(b, key, sc));
+    best[R - 1] = __float_as_uint(fminf(b, key));
+  }
   uint2* out = scratch + (size_t)split * split_stride + job.out_off;
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const u32 qi = q0 + r * 64 + lane;
-    if (FILL == 5) {
+    if (FILL >= 5) {
       best[r] = fkey_to_key(best[r], t0);
       second[r] = fkey_to_key(second[r], t0);
     }
