@@ -130,23 +130,33 @@ __global__ __launch_bounds__(256) void gftt_candidates_kernel(const float* __res
 // permutation.  n^2 / 2^14 lane-iterations: 15 k candidates take ~25 us, against ~1 ms for a
 // host sort; the host falls back to std::sort above GFTT_RANK_SORT_MAX.
 constexpr u32 GFTT_RANK_SORT_MAX = 65536;
-__global__ __launch_bounds__(256) void gftt_rank_sort_kernel(const u64* __restrict__ cand,
-                                                             const u32* __restrict__ count, u32 cap,
-                                                             u64* __restrict__ sorted) {
+constexpr u32 GFTT_RANK_BLOCK = 64;  // one wave per workgroup: 15 k candidates still cover ~all 256 CUs
+__global__ __launch_bounds__(GFTT_RANK_BLOCK) void gftt_rank_sort_kernel(const u64* __restrict__ cand,
+                                                                         const u32* __restrict__ count, u32 cap,
+                                                                         u64* __restrict__ sorted) {
   __shared__ u64 tile[256];
   const u32 n = min(*count, cap);
-  if (n > GFTT_RANK_SORT_MAX || blockIdx.x * 256 >= n) return;  // block-uniform
-  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (n > GFTT_RANK_SORT_MAX || blockIdx.x * GFTT_RANK_BLOCK >= n) return;  // block-uniform
+  const u32 i = blockIdx.x * GFTT_RANK_BLOCK + threadIdx.x;
   const u64 mine = i < n ? cand[i] : 0;
-  u32 rank = 0;
+  u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
   for (u32 base = 0; base < n; base += 256) {
     __syncthreads();
-    tile[threadIdx.x] = base + threadIdx.x < n ? cand[base + threadIdx.x] : 0;  // 0 is below every real key
+#pragma unroll
+    for (u32 k = 0; k < 256; k += GFTT_RANK_BLOCK) {
+      const u32 j = base + k + threadIdx.x;
+      tile[k + threadIdx.x] = j < n ? cand[j] : 0;  // 0 is below every real key
+    }
     __syncthreads();
-#pragma unroll 8
-    for (u32 j = 0; j < 256; j++) rank += tile[j] > mine ? 1u : 0u;
+#pragma unroll 4
+    for (u32 j = 0; j < 256; j += 4) {  // four independent counters: the compares do not serialise
+      r0 += tile[j] > mine ? 1u : 0u;
+      r1 += tile[j + 1] > mine ? 1u : 0u;
+      r2 += tile[j + 2] > mine ? 1u : 0u;
+      r3 += tile[j + 3] > mine ? 1u : 0u;
+    }
   }
-  if (i < n) sorted[rank] = mine;
+  if (i < n) sorted[(r0 + r1) + (r2 + r3)] = mine;
 }
 
 }  // namespace vsm

@@ -940,8 +940,8 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
                      (const u32*)d_misc, quality, (u64*)(d + o_cand), d_misc + 1, (u32)n);
   // order them on the device (the gradient area is free again); sized for the largest count the
   // kernel sorts -- it reads the real count itself, so no host round trip is needed in between
-  const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + 255) / 256);
-  hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks), dim3(256), 0, c->stream, (const u64*)(d + o_cand),
+  const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + GFTT_RANK_BLOCK - 1) / GFTT_RANK_BLOCK);
+  hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks), dim3(GFTT_RANK_BLOCK), 0, c->stream, (const u64*)(d + o_cand),
                      (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad));
   HIP_TRY(hipGetLastError());
   // one speculative download: the count and the first GFTT_FIRST_COPY ordered candidates
