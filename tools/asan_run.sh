@@ -1,0 +1,35 @@
+#!/bin/bash
+# Runs the three C++ shim tests against a host-AddressSanitizer build of libvsmatch
+# (tools/asan_build/, built in the container with `hipcc -Xarch_host -fsanitize=address`;
+# device code is not instrumented).  Run on the GPU box through gpurun.
+# Build first (container):
+#   mkdir -p tools/asan_build && cd tools/asan_build
+#   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -Xarch_host -fsanitize=address \
+#         -I../../include -I../../visual-slam_amd/csrc ../../visual-slam_amd/csrc/vsmatch.hip -o libvsmatch.so
+#   for t in shim_test shim_landmarks_test shim_orb_test; do /opt/rocm/lib/llvm/bin/clang++ -std=c++14 -O1 -g \
+#         -fsanitize=address -I../../include ../../tests/cpp/$t.cpp -L. -lvsmatch -pthread -Wl,-rpath,'$ORIGIN' -o $t; done
+# Result of round 1 (gpurun_out/asan.log): all four runs clean; delete tools/asan_build afterwards (12 MB).
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+D=$(mktemp -d)
+python3 - "$D" <<'PY'
+import os, sys, numpy as np
+sys.path.insert(0, ".")
+from tests.test_landmarks_oracle import ex5
+from tests.test_orb_oracle import ex3_image, ex3_kd
+d = sys.argv[1]
+os.makedirs(d + "/lm"); os.makedirs(d + "/orb")
+g = ex5()
+for k in ("kp_desc", "kp_xy", "proj_xy", "track_ids", "obs_off", "obs_desc", "expected"):
+    np.ascontiguousarray(g[k]).tofile(f"{d}/lm/{k}.bin")
+xy, ang, desc = ex3_kd(0); img = ex3_image(0)
+np.ascontiguousarray(img).tofile(d + "/orb/img.bin"); np.array([img.shape[1], img.shape[0]], np.int32).tofile(d + "/orb/dims.bin")
+xy.tofile(d + "/orb/corners.bin"); ang.tofile(d + "/orb/angles.bin"); desc.tofile(d + "/orb/desc.bin")
+PY
+export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
+G=tests/golden
+timeout -k 10 120 tools/asan_build/shim_test $G/ex3_kd0.npy $G/ex3_kd1.npy $G/ex3_matches.npy
+timeout -k 10 120 tools/asan_build/shim_landmarks_test $D/lm
+timeout -k 10 120 tools/asan_build/shim_orb_test $D/orb
+timeout -k 10 120 tools/asan_build/shim_orb_test $D/orb detect
+echo "asan: all shim tests clean"
