@@ -391,6 +391,33 @@ def main():
             "bit_exact_vs_cpu": bool(np.array_equal(dxy, cxy) and np.array_equal(da, ca2) and np.array_equal(dd, cd2)),
             "note": "Sobel/min-eigenvalue/local-maxima kernels + host ordering and min-distance pass + ORB kernels; "
                     "the CPU figure is the plain-C port, not OpenCV's SIMD code"}
+        # one odometry keyframe's GPU front end on a real EuRoC stereo frame (odometry.cpp:797-835):
+        # detectKeypointsAndDescriptors x 2, matchDescriptors(kdl, kdr, 70, 1.2), find_matches_landmarks
+        try:
+            from PIL import Image
+            sub = os.path.join(ROOT, "tests", "golden", "euroc_subset")
+            names = sorted(f for f in os.listdir(sub) if f.endswith(".jpg"))[:2]
+            il, ir = (np.array(Image.open(os.path.join(sub, f))) for f in names)
+
+            def keyframe():
+                xl, al, dl = m.detect_and_describe(il, 1500, True)
+                xr, ar, dr = m.detect_and_describe(ir, 1500, True)
+                ms = m.match(dl, dr, a.threshold, a.ratio)
+                ml = m.match_landmarks(dl, xl, lf[2], lf[3], lf[4], 20.0, a.threshold, a.ratio)
+                return len(xl), len(xr), len(ms), len(ml)
+
+            for _ in range(5):
+                kf = keyframe()
+            t = time.perf_counter()
+            for _ in range(30):
+                kf = keyframe()
+            extra["odometry_keyframe_frontend_real_euroc_frame"] = {
+                "latency_ms_host_to_host": (time.perf_counter() - t) / 30 * 1e3, "corners_left_right": kf[:2],
+                "stereo_matches": kf[2], "landmark_matches_synthetic_map": kf[3],
+                "note": "4 library calls per keyframe: 2 x (detect + angles + descriptors), stereo match, landmark match "
+                        "(2500 synthetic projected landmarks); images from tests/golden/euroc_subset"}
+        except (OSError, ImportError):
+            pass
         # config 3 shape: 164 images (82 stereo frames) of 1200-1500 descriptors, the 13284
         # non-stereo pairs of sfm.cpp:1285-1290 in one batch
         sz = np.random.default_rng(3).integers(1200, 1501, size=164)
