@@ -48,7 +48,7 @@ def test_pair_matches_recorded_reference(m, name):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
-                                     0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008])
+                                     0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008, 0x1000008, 0x1020008])
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
     tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
@@ -239,12 +239,13 @@ def test_adaptive_tiles_on_ragged_database(m):
     pairs = np.concatenate([pairs, pairs[:, ::-1]])  # both orientations
     m.db_upload(db, off)
     offs, lists = m.match_pairs(pairs, 70, 1.2)
-    m.set_variant(0x40000)
-    try:
-        offs_fixed, lists_fixed = m.match_pairs(pairs, 70, 1.2)
-    finally:
-        m.set_variant(0)
-    assert np.array_equal(offs, offs_fixed) and np.array_equal(lists, lists_fixed)
+    for variant in (0x40000, 0x1000000):  # fixed 512-query tiles; adaptive tiles in 4-wave workgroups
+        m.set_variant(variant)
+        try:
+            offs_v, lists_v = m.match_pairs(pairs, 70, 1.2)
+        finally:
+            m.set_variant(0)
+        assert np.array_equal(offs, offs_v) and np.array_equal(lists, lists_v), variant
     assert len(lists) > 20000
     o = binding.port()
     for k in range(0, len(pairs), 7):

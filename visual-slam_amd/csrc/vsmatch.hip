@@ -221,6 +221,7 @@ struct ScanShape {
   u32 wgs_per_job, splits;
   bool fkey;      // float-key tracking (scan range per split <= FKEY_MAX_SET)
   bool adaptive;  // scan_kernel_adaptive: 512-query tiles + 256/128/64 remainder tiles (R == 8 only)
+  u32 tiles;      // most tiles a job has (adaptive: grid of one-wave workgroups = n_jobs x tiles)
 };
 
 // Most tiles scan_kernel_adaptive can need for a job of at most max_nq queries (the tile
@@ -252,6 +253,7 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exac
   s.adaptive = s.R == 8 && !(variant & 0x40000);
   const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles : adaptive_tiles_bound(max_nq))
                                : (max_nq + tq - 1) / tq;
+  s.tiles = std::max(1u, tiles);
   s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
   const u64 waves = std::max<u64>(1, n_jobs * tiles);
   // (a) latency regime: reach TARGET_WAVES with at least 64 train items per split;
@@ -294,15 +296,31 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   // measured in profiles/r01/scan_variants*.txt.
   const int fill = !sh.fkey ? 2 : (c->variant & 0x80000) ? 5 : 7;
   if (sh.adaptive) {
-    if (fill == 7)
-      hipLaunchKernelGGL((scan_kernel_adaptive<7>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
-                         split_stride, d_scratch, d_qlist);
-    else if (fill == 5)
-      hipLaunchKernelGGL((scan_kernel_adaptive<5>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
-                         split_stride, d_scratch, d_qlist);
-    else
-      hipLaunchKernelGGL((scan_kernel_adaptive<2>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits,
-                         split_stride, d_scratch, d_qlist);
+    // One wave per workgroup: the tiles of a ragged job run 1..8 x as long as each other, and a
+    // 4-wave workgroup can only start when a slot is free on every SIMD at once -- with
+    // one-wave workgroups any freed slot is refilled (tools/ragged_probe.py: 1537 -> 2065 G
+    // comparisons/s at euroc_V1's image sizes, unchanged on uniform ones).  Bit 24 of the
+    // experiment knob: the 4-wave form.
+    const bool w1 = !(c->variant & 0x1000000);
+    dim3 agrid = grid, ablock = block;
+    if (w1) {
+      const u64 blocks1 = n_jobs * sh.tiles;
+      if (blocks1 > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks1);
+      agrid = dim3((u32)blocks1, sh.splits);
+      ablock = dim3(64);
+    }
+#define VSM_LAUNCH_A(FF, WW)                                                                         \
+  hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
+                     sh.splits, split_stride, d_scratch, d_qlist)
+    switch (fill * 2 + (w1 ? 1 : 0)) {
+      case 14: VSM_LAUNCH_A(7, 4); break;
+      case 15: VSM_LAUNCH_A(7, 1); break;
+      case 10: VSM_LAUNCH_A(5, 4); break;
+      case 11: VSM_LAUNCH_A(5, 1); break;
+      case 4: VSM_LAUNCH_A(2, 4); break;
+      default: VSM_LAUNCH_A(2, 1); break;
+    }
+#undef VSM_LAUNCH_A
   } else
   switch (sh.R * 16 + fill) {
     case 16 + 2: VSM_LAUNCH(1, 2); break;

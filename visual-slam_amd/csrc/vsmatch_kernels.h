@@ -303,19 +303,19 @@ __host__ __device__ inline u32 adaptive_tiles(u32 nq) {
   const u32 n64 = (nq + 63) >> 6, rem = n64 & 7;
   return (n64 >> 3) + ((rem >> 2) & 1) + ((rem >> 1) & 1) + (rem & 1);
 }
-template <int FILL>
-__global__ __launch_bounds__(256) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
-                                                            const u32x4* __restrict__ tbase,
-                                                            const Job* __restrict__ jobs, u32 n_jobs,
-                                                            u32 splits, u32 split_stride,
-                                                            uint2* __restrict__ scratch,
-                                                            const u32* __restrict__ qlist) {
+template <int FILL, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
+                                                                   const u32x4* __restrict__ tbase,
+                                                                   const Job* __restrict__ jobs, u32 n_jobs,
+                                                                   u32 splits, u32 split_stride,
+                                                                   uint2* __restrict__ scratch,
+                                                                   const u32* __restrict__ qlist) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   const u32 wg_of_job = blockIdx.x / n_jobs;
   const u32 job_id = blockIdx.x - wg_of_job * n_jobs;
   const Job job = jobs[job_id];
-  const u32 t = wg_of_job * 4 + wave;
+  const u32 t = wg_of_job * WAVES + wave;
   const u32 n64 = (job.nq + 63) >> 6, full = n64 >> 3, rem = n64 & 7;
   if (t < full) {
     scan_tile<8, FILL>(qbase, tbase, job, t * 512, lane, blockIdx.y, splits, split_stride, scratch, qlist);
