@@ -119,6 +119,7 @@ struct vsm_ctx {
   std::vector<u32> img_off;
   u32 max_n = 0;
   u32 max_tiles = 0;  // most adaptive tiles any image of the database needs
+  bool uniform_tiles = false;  // ... and every image needs exactly that many
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
@@ -222,6 +223,7 @@ struct ScanShape {
   bool fkey;      // float-key tracking (scan range per split <= FKEY_MAX_SET)
   bool adaptive;  // scan_kernel_adaptive: 512-query tiles + 256/128/64 remainder tiles (R == 8 only)
   u32 tiles;      // most tiles a job has (adaptive: grid of one-wave workgroups = n_jobs x tiles)
+  bool uniform;   // every job has exactly `tiles` tiles (grouped block order, see the kernel)
 };
 
 // Most tiles scan_kernel_adaptive can need for a job of at most max_nq queries (the tile
@@ -236,7 +238,8 @@ u32 adaptive_tiles_bound(u32 max_nq) {
 // Queries per wave (64*R) and train splits.  Large batches: R = 4, no split.
 // Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
 // query per lane and the train range split over grid.y so that all 256 CUs work.
-ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exact_max_tiles = 0) {
+ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exact_max_tiles = 0,
+                       bool uniform_tiles = false) {
   ScanShape s;
   // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
   // override, bit 17 = integer-key tracking everywhere
@@ -254,6 +257,7 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exac
   const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles : adaptive_tiles_bound(max_nq))
                                : (max_nq + tq - 1) / tq;
   s.tiles = std::max(1u, tiles);
+  s.uniform = uniform_tiles && exact_max_tiles != 0;
   s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
   const u64 waves = std::max<u64>(1, n_jobs * tiles);
   // (a) latency regime: reach TARGET_WAVES with at least 64 train items per split;
@@ -304,14 +308,14 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
     const bool w1 = !(c->variant & 0x1000000);
     dim3 agrid = grid, ablock = block;
     if (w1) {
-      const u64 blocks1 = n_jobs * sh.tiles;
+      const u64 blocks1 = (sh.uniform ? (n_jobs + 7) / 8 * 8 : n_jobs) * sh.tiles;
       if (blocks1 > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks1);
       agrid = dim3((u32)blocks1, sh.splits);
       ablock = dim3(64);
     }
 #define VSM_LAUNCH_A(FF, WW)                                                                         \
   hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist)
+                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
     switch (fill * 2 + (w1 ? 1 : 0)) {
       case 14: VSM_LAUNCH_A(7, 4); break;
       case 15: VSM_LAUNCH_A(7, 1); break;
@@ -367,7 +371,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     return VSM_OK;
   }
   const u32 stride = std::max(64u, round_up(max_n, 64));
-  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : 0);
+  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : 0,
+                                    d_desc == c->db && c->uniform_tiles);
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
@@ -453,11 +458,12 @@ int check_ctx(vsm_ctx* c) {
 int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
   if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
   if (n_img >= 0xffffffffull) return fail(VSM_ERR_INVALID, "too many images");
-  u32 max_n = 0, max_tiles = 0;
+  u32 max_n = 0, max_tiles = 0, min_tiles = 0xffffffffu;
   for (size_t i = 0; i < n_img; i++) {
     if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
     max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
     max_tiles = std::max(max_tiles, adaptive_tiles(offsets[i + 1] - offsets[i]));
+    min_tiles = std::min(min_tiles, adaptive_tiles(offsets[i + 1] - offsets[i]));
   }
   if (max_n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "image with %u descriptors exceeds VSM_MAX_SET", max_n);
   if (n_img && !d_desc && offsets[n_img] != 0) return fail(VSM_ERR_INVALID, "null descriptor pointer");
@@ -467,6 +473,7 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
   c->img_off.assign(offsets, offsets + n_img + 1);
   c->max_n = max_n;
   c->max_tiles = max_tiles;
+  c->uniform_tiles = n_img > 0 && min_tiles == max_tiles;
   c->db = d_desc;
   return VSM_OK;
 }

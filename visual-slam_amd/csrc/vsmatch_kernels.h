@@ -303,19 +303,39 @@ __host__ __device__ inline u32 adaptive_tiles(u32 nq) {
   const u32 n64 = (nq + 63) >> 6, rem = n64 & 7;
   return (n64 >> 3) + ((rem >> 2) & 1) + ((rem >> 1) & 1) + (rem & 1);
 }
+// WAVES == 1 (the shipped form): one-wave workgroups.  Two block orders:
+//  * grouped (tiles_per_job > 0; used when every job has the same number of tiles):
+//    blockIdx.x = (group of 8 jobs, tile, job in group).  Workgroups are dealt round-robin to
+//    the 8 XCDs, so all tiles of a job land on the same XCD within 8 * tiles consecutive
+//    dispatches and its L2 serves the train set to every tile after the first (FETCH_SIZE
+//    3.4 -> 0.9 GB per 16384-pair launch against job-minor order).
+//  * job-minor (tiles_per_job == 0; ragged jobs): blockIdx.x = tile * n_jobs + job.  The idle
+//    workgroups of jobs with fewer tiles then all sit at the end of the grid; interleaved with
+//    the live ones (grouped order) they cost a ragged batch 2.5x (measured, tools/ragged_probe).
+// WAVES == 4: 4-wave workgroups in job-minor order.
 template <int FILL, int WAVES = 4>
 __global__ __launch_bounds__(64 * WAVES) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
                                                                    const u32x4* __restrict__ tbase,
                                                                    const Job* __restrict__ jobs, u32 n_jobs,
                                                                    u32 splits, u32 split_stride,
                                                                    uint2* __restrict__ scratch,
-                                                                   const u32* __restrict__ qlist) {
+                                                                   const u32* __restrict__ qlist,
+                                                                   u32 tiles_per_job) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  const u32 wg_of_job = blockIdx.x / n_jobs;
-  const u32 job_id = blockIdx.x - wg_of_job * n_jobs;
+  u32 job_id, t;
+  if (WAVES == 1 && tiles_per_job) {
+    const u32 per_group = 8 * tiles_per_job;
+    const u32 group = blockIdx.x / per_group, r = blockIdx.x - group * per_group;
+    t = r >> 3;
+    job_id = group * 8 + (r & 7);
+    if (job_id >= n_jobs) return;
+  } else {
+    const u32 wg_of_job = blockIdx.x / n_jobs;
+    job_id = blockIdx.x - wg_of_job * n_jobs;
+    t = wg_of_job * WAVES + wave;
+  }
   const Job job = jobs[job_id];
-  const u32 t = wg_of_job * WAVES + wave;
   const u32 n64 = (job.nq + 63) >> 6, full = n64 >> 3, rem = n64 & 7;
   if (t < full) {
     scan_tile<8, FILL>(qbase, tbase, job, t * 512, lane, blockIdx.y, splits, split_stride, scratch, qlist);
