@@ -327,7 +327,7 @@ def main():
         m.set_profiling(False)
         extra["stereo_1500x1500"] = {"latency_ms_host_to_host": lat * 1e3, "scan_kernel_ms": scan_only,
                                      "matches": int(len(res)), "reference_equivalent_gcomps": 2 * 1500 * 1500 / lat / 1e9,
-                                     "note": "host pointers in, host list out: H2D + 6 kernels + D2H, PCIe inclusive"}
+                                     "note": "host pointers in, host list out: H2D + 3 kernels (scan, merge, emit) + D2H, PCIe inclusive"}
         # next row N1: one odometry frame of find_matches_landmarks
         # (vo_utils.h:95-187, odometry.cpp:832): 1500 keypoints x 2500 projected landmarks,
         # radius 20 px (odometry.cpp:177), host pointers in/out; CPU = the C oracle, 1 thread

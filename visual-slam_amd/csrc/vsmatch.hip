@@ -661,10 +661,6 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   const ScanShape sh = choose_shape(2, (u32)std::max(n1, n2), (u32)std::max(n1, n2), c->variant);
   const u32 split_stride = 2 * stride;
   VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
-  VSM_TRY(c->counts.reserve(64));
-  VSM_TRY(c->misc.reserve(64));
-  u64* d_running = (u64*)c->misc.p;
-  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 16, c->stream));
   VSM_TRY(launch_scan(c, c->stage.p, c->stage.p, d_jobs, 2, sh, split_stride, (uint2*)c->scratch.p,
                       2ull * n1 * n2));
   u64* d_off = (u64*)c->w_out.p;
@@ -672,12 +668,8 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   if (sh.splits > 1)
     hipLaunchKernelGGL(merge_splits_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream,
                        (uint2*)c->scratch.p, split_stride, sh.splits, split_stride);
-  hipLaunchKernelGGL(count_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
-                     1u, split_stride, prm, (u32*)c->counts.p);
-  hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->counts.p, 1u,
-                     d_off, (u64)0, d_running);
-  hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
-                     1u, split_stride, prm, (const u64*)d_off, (u64)0, d_out, (u64)nmin);
+  hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
+                     split_stride, prm, d_off, d_out, (u64)nmin);
   HIP_TRY(hipGetLastError());
   char* hd = h + up_bytes;
   HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -511,6 +511,45 @@ __global__ __launch_bounds__(256) void fill_kernel(const Job* __restrict__ jobs,
   }
 }
 
+// Single pair (vsm_match_pair, the odometry / match_stereo call): accept test, cross-check and
+// ordered emission in ONE single-workgroup kernel instead of count + scan_counts + fill (three
+// launches, ~22 us of a ~80 us call).  out_count[0] = number of matches; pairs from out_pairs[0].
+// jobs[0] = forward job, jobs[1] = backward job; scratch holds the merged results (splits folded).
+__global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ jobs,
+                                                        const uint2* __restrict__ scratch, u32 split_stride,
+                                                        AcceptParams prm, u64* __restrict__ out_count,
+                                                        int2* __restrict__ out_pairs, u64 cap_pairs) {
+  __shared__ uint16_t lut[260];
+  __shared__ u32 wave_cnt[4];
+  load_lut(lut, prm);
+  const Job f = jobs[0], b = jobs[1];
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 done = 0;
+  for (u32 base = 0; base < f.nq; base += 256) {
+    const u32 i = base + threadIdx.x;
+    u32 j = 0;
+    const bool hit = cross_check(scratch, f, b, i, 1u, split_stride, lut, prm.threshold, j);
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = done, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
+    }
+    if (hit) {
+      const u64 pos = before + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      if (pos < cap_pairs) out_pairs[pos] = make_int2((int)i, (int)j);
+    }
+    done += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out_count[0] = 0;
+    out_count[1] = done;  // same layout as the offsets pair {0, count} the host reads
+  }
+}
+
 // jobs[p], jobs[n_pairs + p] for pair p = (pairs[p].x, pairs[p].y) of the database.
 // A pair naming an image >= n_img raises *bad and becomes an empty job pair.
 __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
