@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void orb_descriptor_kernel(const uint8_t* __re
 #pragma clang fp contract(off)
   const u32 k = blockIdx.x;
   const u32 di = threadIdx.x;
+  if (k >= n) return;
   const double2 p = corners[k];
   const int cx = (int)p.x, cy = (int)p.y;  // keypoints.h:213-214
   const double c = cs[k].x, s = cs[k].y;
