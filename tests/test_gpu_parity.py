@@ -252,3 +252,31 @@ def test_adaptive_tiles_on_ragged_database(m):
         i, j = pairs[k]
         want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
         assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want), (k, i, j)
+
+
+def test_fuzz_random_shapes_and_parameters(m):
+    """200 seeded random cases: sizes 0..400 per side, threshold 1..300, ratio 0.5..4, planted or
+    dense duplicates -- single-pair call against the oracle, and the same pairs once more through
+    the batched call."""
+    rng = np.random.default_rng(20251110)
+    o = binding.port()
+    sets, params, want = [], [], []
+    for k in range(200):
+        n1, n2 = (int(v) for v in rng.integers(0, 401, 2))
+        a, b = cases.synth.orb_like_pair(max(n1, 1), max(n2, 1), seed=1000 + k, match_frac=float(rng.uniform(0, 1)),
+                                         dup_frac=float(rng.uniform(0, 0.3)), confuse_frac=float(rng.uniform(0, 0.3)))
+        a, b = a[:n1], b[:n2]
+        thr, ratio = int(rng.integers(1, 301)), float(rng.uniform(0.5, 4.0))
+        w = o.match(a, b, thr, ratio)
+        assert np.array_equal(m.match(a, b, thr, ratio), w), (k, n1, n2, thr, ratio)
+        sets += [a, b]
+        params.append((thr, ratio))
+        want.append(w)
+    off = np.zeros(len(sets) + 1, np.uint32)
+    off[1:] = np.cumsum([len(s) for s in sets])
+    m.db_upload(np.concatenate(sets), off)
+    pairs = np.arange(400, dtype=np.uint32).reshape(200, 2)
+    for thr, ratio in ((70, 1.2), (90, 1.0)):
+        offs, lists = m.match_pairs(pairs, thr, ratio)
+        for k in range(0, 200, 3):
+            assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], o.match(sets[2 * k], sets[2 * k + 1], thr, ratio)), k
