@@ -262,7 +262,7 @@ def main():
     assert 0 < scan_comps <= comps_rank, (scan_comps, comps_rank)
     achieved = fwd["comparisons"] * LANE_OPS_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
     roofline = {
-        "bound": "valu", "kernel": "scan_kernel_adaptive<7> (forward scans, the dominant kernel: 512-query tiles, float keys)",
+        "bound": "valu", "kernel": "scan_kernel_adaptive<8,1,4> (forward scans, the dominant kernel: one-wave workgroups, 256-query tiles, float keys, skip test)",
         "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlaneop/s", "frac": achieved / PEAK_TLANEOPS,
         "frac_of_nominal_64_lanes_per_clk_peak": achieved / NOMINAL_TLANEOPS,
         "traffic": None,

@@ -52,8 +52,9 @@ def test_pair_matches_recorded_reference(m, name):
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
     tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
-    decomposition unless bit 18 is set; bit 19 selects the plain float-key sequence FILL 5
-    instead of FILL 7) gives the same list."""
+    decomposition (256-query tiles, skip test) unless bit 18 is set; bits 19 / 24 select its
+    earlier forms: 512-query tiles without the skip test, one-wave / 4-wave workgroups) gives
+    the same list."""
     m.set_variant(variant)
     try:
         for name in ("ex3_thr70_r1.2", "planted_300x777", "planted_1023x1025", "planted_4100x130",
@@ -239,7 +240,7 @@ def test_adaptive_tiles_on_ragged_database(m):
     pairs = np.concatenate([pairs, pairs[:, ::-1]])  # both orientations
     m.db_upload(db, off)
     offs, lists = m.match_pairs(pairs, 70, 1.2)
-    for variant in (0x40000, 0x1000000):  # fixed 512-query tiles; adaptive tiles in 4-wave workgroups
+    for variant in (0x40000, 0x80000, 0x1000000):  # fixed 512-query tiles; 512-query adaptive tiles, 1- and 4-wave
         m.set_variant(variant)
         try:
             offs_v, lists_v = m.match_pairs(pairs, 70, 1.2)

@@ -118,8 +118,8 @@ struct vsm_ctx {
   DevBuf d_img_off;
   std::vector<u32> img_off;
   u32 max_n = 0;
-  u32 max_tiles = 0;  // most adaptive tiles any image of the database needs
-  bool uniform_tiles = false;  // ... and every image needs exactly that many
+  u32 max_tiles[2] = {0, 0};  // most adaptive tiles any image of the database needs, for rmax = 8, 4
+  bool uniform_tiles[2] = {false, false};  // ... and every image needs exactly that many
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
@@ -224,22 +224,23 @@ struct ScanShape {
   bool adaptive;  // scan_kernel_adaptive: 512-query tiles + 256/128/64 remainder tiles (R == 8 only)
   u32 tiles;      // most tiles a job has (adaptive: grid of one-wave workgroups = n_jobs x tiles)
   bool uniform;   // every job has exactly `tiles` tiles (grouped block order, see the kernel)
+  int rmax;       // adaptive: queries per lane of the full tiles (4 shipped, 8 with knob bits 19/24)
 };
 
 // Most tiles scan_kernel_adaptive can need for a job of at most max_nq queries (the tile
 // count is not monotone in nq: 448 queries are 3 tiles, 512 are 1).
-u32 adaptive_tiles_bound(u32 max_nq) {
+u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
   const u32 n64 = (max_nq + 63) >> 6;
   u32 best = 0;
-  for (u32 k = n64 > 16 ? n64 - 16 : 0; k <= n64; k++) best = std::max(best, adaptive_tiles(k * 64));
+  for (u32 k = n64 > 16 ? n64 - 16 : 0; k <= n64; k++) best = std::max(best, adaptive_tiles(k * 64, rmax));
   return best;
 }
 
 // Queries per wave (64*R) and train splits.  Large batches: R = 4, no split.
 // Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
 // query per lane and the train range split over grid.y so that all 256 CUs work.
-ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exact_max_tiles = 0,
-                       bool uniform_tiles = false) {
+ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u32* exact_max_tiles = nullptr,
+                       const bool* uniform_tiles = nullptr) {
   ScanShape s;
   // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
   // override, bit 17 = integer-key tracking everywhere
@@ -254,10 +255,13 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, u32 exac
   const u32 tq = 64 * s.R;
   // bit 18 of the experiment knob: fixed 512-query tiles instead of the adaptive decomposition
   s.adaptive = s.R == 8 && !(variant & 0x40000);
-  const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles : adaptive_tiles_bound(max_nq))
+  // bits 19 / 24: the earlier forms (512-query tiles without the skip test; 4-wave workgroups)
+  s.rmax = (variant & (0x80000 | 0x1000000)) ? 8 : 4;
+  const int ri = s.rmax == 8 ? 0 : 1;  // index into the per-database tile statistics
+  const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles[ri] : adaptive_tiles_bound(max_nq, (u32)s.rmax))
                                : (max_nq + tq - 1) / tq;
   s.tiles = std::max(1u, tiles);
-  s.uniform = uniform_tiles && exact_max_tiles != 0;
+  s.uniform = s.adaptive && uniform_tiles && exact_max_tiles && uniform_tiles[ri];
   s.wgs_per_job = std::max(1u, (tiles + 3) / 4);
   const u64 waves = std::max<u64>(1, n_jobs * tiles);
   // (a) latency regime: reach TARGET_WAVES with at least 64 train items per split;
@@ -295,10 +299,10 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
                      sh.splits, split_stride, d_scratch, d_qlist)
   // Float-key tracking (train range per split <= 32768): FILL 7 (key construction in the next
-  // chain's filler slots; FILL 5, the plain float-key sequence, with bit 19 of the experiment
-  // knob); integer keys with a v_mov filler behind every v_bcnt otherwise (FILL 2).  All
-  // measured in profiles/r01/scan_variants*.txt.
-  const int fill = !sh.fkey ? 2 : (c->variant & 0x80000) ? 5 : 7;
+  // chain's filler slots), in the adaptive kernel FILL 8 (FILL 7 + wave-level skip of the
+  // tracking pair); integer keys with a v_mov filler behind every v_bcnt otherwise (FILL 2).
+  // All measured in profiles/r01/scan_variants*.txt.
+  const int fill = !sh.fkey ? 2 : 7;
   if (sh.adaptive) {
     // One wave per workgroup: the tiles of a ragged job run 1..8 x as long as each other, and a
     // 4-wave workgroup can only start when a slot is free on every SIMD at once -- with
@@ -313,31 +317,30 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
       agrid = dim3((u32)blocks1, sh.splits);
       ablock = dim3(64);
     }
-#define VSM_LAUNCH_A(FF, WW)                                                                         \
-  hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
+#define VSM_LAUNCH_A(FF, WW, RR)                                                                     \
+  hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW, RR>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
                      sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
-    switch (fill * 2 + (w1 ? 1 : 0)) {
-      case 14: VSM_LAUNCH_A(7, 4); break;
-      case 15: VSM_LAUNCH_A(7, 1); break;
-      case 10: VSM_LAUNCH_A(5, 4); break;
-      case 11: VSM_LAUNCH_A(5, 1); break;
-      case 4: VSM_LAUNCH_A(2, 4); break;
-      default: VSM_LAUNCH_A(2, 1); break;
+    if (fill == 2) {  // integer keys (a split scans more than 32768 train descriptors)
+      if (sh.rmax == 4) VSM_LAUNCH_A(2, 1, 4);
+      else if (w1) VSM_LAUNCH_A(2, 1, 8);
+      else VSM_LAUNCH_A(2, 4, 8);
+    } else if (sh.rmax == 4) {
+      VSM_LAUNCH_A(8, 1, 4);  // shipped: 256-query tiles, FILL 8, one-wave workgroups
+    } else if (w1) {
+      VSM_LAUNCH_A(7, 1, 8);
+    } else {
+      VSM_LAUNCH_A(7, 4, 8);
     }
 #undef VSM_LAUNCH_A
   } else
   switch (sh.R * 16 + fill) {
     case 16 + 2: VSM_LAUNCH(1, 2); break;
-    case 16 + 5: VSM_LAUNCH(1, 5); break;
     case 16 + 7: VSM_LAUNCH(1, 7); break;
     case 32 + 2: VSM_LAUNCH(2, 2); break;
-    case 32 + 5: VSM_LAUNCH(2, 5); break;
     case 32 + 7: VSM_LAUNCH(2, 7); break;
     case 64 + 2: VSM_LAUNCH(4, 2); break;
-    case 64 + 5: VSM_LAUNCH(4, 5); break;
     case 64 + 7: VSM_LAUNCH(4, 7); break;
     case 128 + 2: VSM_LAUNCH(8, 2); break;
-    case 128 + 5: VSM_LAUNCH(8, 5); break;
     case 128 + 7: VSM_LAUNCH(8, 7); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
   }
@@ -371,8 +374,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     return VSM_OK;
   }
   const u32 stride = std::max(64u, round_up(max_n, 64));
-  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : 0,
-                                    d_desc == c->db && c->uniform_tiles);
+  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : nullptr,
+                                    d_desc == c->db ? c->uniform_tiles : nullptr);
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
@@ -458,12 +461,15 @@ int check_ctx(vsm_ctx* c) {
 int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
   if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
   if (n_img >= 0xffffffffull) return fail(VSM_ERR_INVALID, "too many images");
-  u32 max_n = 0, max_tiles = 0, min_tiles = 0xffffffffu;
+  u32 max_n = 0, max_tiles[2] = {0, 0}, min_tiles[2] = {0xffffffffu, 0xffffffffu};
   for (size_t i = 0; i < n_img; i++) {
     if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
     max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
-    max_tiles = std::max(max_tiles, adaptive_tiles(offsets[i + 1] - offsets[i]));
-    min_tiles = std::min(min_tiles, adaptive_tiles(offsets[i + 1] - offsets[i]));
+    for (int ri = 0; ri < 2; ri++) {
+      const u32 tl = adaptive_tiles(offsets[i + 1] - offsets[i], ri == 0 ? 8u : 4u);
+      max_tiles[ri] = std::max(max_tiles[ri], tl);
+      min_tiles[ri] = std::min(min_tiles[ri], tl);
+    }
   }
   if (max_n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "image with %u descriptors exceeds VSM_MAX_SET", max_n);
   if (n_img && !d_desc && offsets[n_img] != 0) return fail(VSM_ERR_INVALID, "null descriptor pointer");
@@ -472,8 +478,10 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->img_off.assign(offsets, offsets + n_img + 1);
   c->max_n = max_n;
-  c->max_tiles = max_tiles;
-  c->uniform_tiles = n_img > 0 && min_tiles == max_tiles;
+  for (int ri = 0; ri < 2; ri++) {
+    c->max_tiles[ri] = max_tiles[ri];
+    c->uniform_tiles[ri] = n_img > 0 && min_tiles[ri] == max_tiles[ri];
+  }
   c->db = d_desc;
   return VSM_OK;
 }

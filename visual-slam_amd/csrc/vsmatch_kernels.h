@@ -113,6 +113,10 @@ __device__ __forceinline__ u32 fkey_to_key(u32 fbits, u32 base) {
 // 27.  Measured (tools/scan_variants, profiles/r01/scan_variants_piggyback.txt): R = 8 +1.6 %,
 // R = 4 +5 % over FILL 5.  v_min_f32 / v_max_f32 / v_med3_f32 do NOT work as fillers (moving
 // them into filler slots too, 24-25 instructions, is slower), only add/mul/fma f32 and v_mov do.
+// FILL == 8 (shipped with 256-query tiles): FILL 7 plus a wave-level test -- the v_med3_f32 /
+// v_min_f32 pair runs only if some lane's key is below its second best (v_cmp_lt_f32 +
+// s_cbranch).  At 4 queries per lane (61 VGPRs, 8 waves per SIMD to cover the branch) this is
+// +4 % over FILL 7 at 8 queries per lane; at 8 queries per lane it loses (128 VGPRs).
 // `Pend` carries the last chain of one call (its popcount result and the bit pattern of
 // 2^23 + j) into the next call; scan_tile flushes it after the last train descriptor.
 struct Pend {
@@ -123,7 +127,7 @@ constexpr u32 PEND_INIT_D = FKEY_MAGIC + 256u;  // distance 256: a key >= FKEY_I
 template <int R, int FILL>
 __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 j, u32 (&best)[R],
                                        u32 (&second)[R], Pend& pend) {
-  if (FILL == 7) {
+  if (FILL == 7 || FILL == 8) {
     const u32 magic = FKEY_MAGIC;
     const float scale = 32768.0f;
     const u32 jf = FKEY_MAGIC + j;
@@ -137,10 +141,20 @@ __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 
           : "=&v"(d), "=v"(df) : "v"(q[r][0] ^ t[0]), "v"(magic), "v"(dprev));
       asm("v_bcnt_u32_b32 %0, %2, %0\n\tv_fma_f32 %1, %3, %4, %5"
           : "+v"(d), "=v"(key) : "v"(q[r][1] ^ t[1]), "v"(df), "v"(scale), "s"(jfp));
-      asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
-          : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
-      best[pr] = nb;
-      second[pr] = ns;
+      if (FILL == 8) {
+        // experiment: skip the tracking pair unless some lane's key beats its second best
+        if (__builtin_amdgcn_ballot_w64(__uint_as_float(key) < __uint_as_float(second[pr])) != 0) {
+          asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
+              : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
+          best[pr] = nb;
+          second[pr] = ns;
+        }
+      } else {
+        asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
+            : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
+        best[pr] = nb;
+        second[pr] = ns;
+      }
 #pragma unroll
       for (int w = 2; w < 8; w++) d = bcnt_acc<2>(q[r][w] ^ t[w], d);
       dprev = d;
@@ -259,7 +273,7 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
     for (; j < t1; ++j) update<R, FILL>(q, tr[j], j - jb, best, second, pend);
   }
 
-  if (FILL == 7) {  // the last chain's tracking is still pending
+  if (FILL == 7 || FILL == 8) {  // the last chain's tracking is still pending
     const float key = fmaf(__uint_as_float(pend.d) - 8388608.0f, 32768.0f, __uint_as_float(pend.jf));
     const float b = __uint_as_float(best[R - 1]), sc = __uint_as_float(second[R - 1]);
     second[R - 1] = __float_as_uint(__builtin_amdgcn_fmed3f(b, key, sc));
@@ -298,10 +312,10 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
 // cut into tiles of 512 (R = 8) and, for the remainder, one tile per set bit of
 // ceil(rest / 64) -- 256, 128, 64 queries (R = 4, 2, 1) -- so that a wave never carries more than
 // 63 idle query slots.  Same grid as scan_kernel; the wave index within the job selects the
-// tile.  adaptive_tiles(nq) on the host gives the number of tiles a job of nq queries has.
-__host__ __device__ inline u32 adaptive_tiles(u32 nq) {
-  const u32 n64 = (nq + 63) >> 6, rem = n64 & 7;
-  return (n64 >> 3) + ((rem >> 2) & 1) + ((rem >> 1) & 1) + (rem & 1);
+// tile.  adaptive_tiles(nq, rmax) on the host gives the number of tiles a job of nq queries has.
+__host__ __device__ inline u32 adaptive_tiles(u32 nq, u32 rmax) {  // rmax = 8 or 4 (a power of two)
+  const u32 n64 = (nq + 63) >> 6, rem = n64 & (rmax - 1);
+  return n64 / rmax + ((rem >> 2) & 1) + ((rem >> 1) & 1) + (rem & 1);
 }
 // WAVES == 1 (the shipped form): one-wave workgroups.  Two block orders:
 //  * grouped (tiles_per_job > 0; used when every job has the same number of tiles):
@@ -313,7 +327,8 @@ __host__ __device__ inline u32 adaptive_tiles(u32 nq) {
 //    workgroups of jobs with fewer tiles then all sit at the end of the grid; interleaved with
 //    the live ones (grouped order) they cost a ragged batch 2.5x (measured, tools/ragged_probe).
 // WAVES == 4: 4-wave workgroups in job-minor order.
-template <int FILL, int WAVES = 4>
+// RMAX: queries per lane of the full tiles (8 -> 512-query tiles, 4 -> 256-query tiles).
+template <int FILL, int WAVES = 4, int RMAX = 8>
 __global__ __launch_bounds__(64 * WAVES) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
                                                                    const u32x4* __restrict__ tbase,
                                                                    const Job* __restrict__ jobs, u32 n_jobs,
@@ -336,14 +351,14 @@ __global__ __launch_bounds__(64 * WAVES) void scan_kernel_adaptive(const u32x4* 
     t = wg_of_job * WAVES + wave;
   }
   const Job job = jobs[job_id];
-  const u32 n64 = (job.nq + 63) >> 6, full = n64 >> 3, rem = n64 & 7;
+  const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
   if (t < full) {
-    scan_tile<8, FILL>(qbase, tbase, job, t * 512, lane, blockIdx.y, splits, split_stride, scratch, qlist);
+    scan_tile<RMAX, FILL>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist);
     return;
   }
   // remainder tiles in the order 256, 128, 64 (those whose bit is set in rem)
-  u32 k = t - full, q0 = full * 512;
-  if (rem & 4) {
+  u32 k = t - full, q0 = full * 64 * RMAX;
+  if (RMAX > 4 && (rem & 4)) {
     if (k == 0) {
       scan_tile<4, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
       return;
