@@ -272,7 +272,7 @@ def main():
                        "peak = 1024 SIMDs x 64 lanes x 2.4 GHz / (8 x 2.32 + 8 x 4.61 measured issue cycles) "
                        "x 16 = 45.4 T lane-ops/s; nominal BASELINE.md peak (64 lanes/clk/CU) = 39.32 T",
         "kernel_gcomps": fwd["comparisons"] / (fwd["scan_ms"] * 1e-3) / 1e9,
-        "backward_pruned": {"kernel": "scan_kernel<1,7>", "launches": bwd["launches"],
+        "backward_pruned": {"kernel": "scan_kernel<1,8>", "launches": bwd["launches"],
                             "avg_launch_ms": bwd["scan_ms"] / max(1, bwd["launches"]),
                             "kernel_gcomps": (bwd["comparisons"] / (bwd["scan_ms"] * 1e-3) / 1e9) if bwd["scan_ms"] else None},
         "evaluated_over_reference_equivalent": scan_comps / comps_rank,

@@ -153,6 +153,7 @@ int main(int argc, char** argv) {
       {"LDS R8 int nofill TT128", scan_kernel_lds<8, 0, 128>, 8},
       {"R8 fill7 add,fma pb", scan_kernel<8, 7>, 8}, {"R4 fill7 add,fma pb", scan_kernel<4, 7>, 4},
       {"R8 fill8 skip test", scan_kernel<8, 8>, 8}, {"R4 fill8 skip test", scan_kernel<4, 8>, 4},
+      {"R2 fill8 skip test", scan_kernel<2, 8>, 2}, {"R1 fill8 skip test", scan_kernel<1, 8>, 1},
       {"R2 fill7 add,fma pb", scan_kernel<2, 7>, 2}, {"R1 fill7 add,fma pb", scan_kernel<1, 7>, 1},
       {"R2 fill5 f32 key", scan_kernel<2, 5>, 2}, {"R1 fill5 f32 key", scan_kernel<1, 5>, 1}, {"R1 fill2", scan_kernel<1, 2>, 1},
   };

@@ -333,13 +333,14 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
     }
 #undef VSM_LAUNCH_A
   } else
-  switch (sh.R * 16 + fill) {
+  // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
+  switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
     case 16 + 2: VSM_LAUNCH(1, 2); break;
-    case 16 + 7: VSM_LAUNCH(1, 7); break;
+    case 16 + 8: VSM_LAUNCH(1, 8); break;
     case 32 + 2: VSM_LAUNCH(2, 2); break;
-    case 32 + 7: VSM_LAUNCH(2, 7); break;
+    case 32 + 8: VSM_LAUNCH(2, 8); break;
     case 64 + 2: VSM_LAUNCH(4, 2); break;
-    case 64 + 7: VSM_LAUNCH(4, 7); break;
+    case 64 + 8: VSM_LAUNCH(4, 8); break;
     case 128 + 2: VSM_LAUNCH(8, 2); break;
     case 128 + 7: VSM_LAUNCH(8, 7); break;
     default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
