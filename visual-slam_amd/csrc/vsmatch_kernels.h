@@ -143,7 +143,7 @@ __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 
           : "+v"(d), "=v"(key) : "v"(q[r][1] ^ t[1]), "v"(df), "v"(scale), "s"(jfp));
       if (FILL == 8) {
         // experiment: skip the tracking pair unless some lane's key beats its second best
-        if (__builtin_amdgcn_ballot_w64(__uint_as_float(key) < __uint_as_float(second[pr])) != 0) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__uint_as_float(key) < __uint_as_float(second[pr])) != 0, 0)) {
           asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
               : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
           best[pr] = nb;
