@@ -240,7 +240,9 @@ def test_adaptive_tiles_on_ragged_database(m):
     pairs = np.concatenate([pairs, pairs[:, ::-1]])  # both orientations
     m.db_upload(db, off)
     offs, lists = m.match_pairs(pairs, 70, 1.2)
-    for variant in (0x40000, 0x80000, 0x1000000):  # fixed 512-query tiles; 512-query adaptive tiles, 1- and 4-wave
+    # fixed 512-query tiles; 512-query adaptive tiles, 1- and 4-wave; forced full-tile sizes 256 / 128 / 64,
+    # the last two also with integer keys
+    for variant in (0x40000, 0x80000, 0x1000000, 0x40000000, 0x20000000, 0x10000000, 0x20020000, 0x10020000):
         m.set_variant(variant)
         try:
             offs_v, lists_v = m.match_pairs(pairs, 70, 1.2)

@@ -18,6 +18,10 @@ DATASETS = [
     ("96 img x 2000 dense, 4560 pairs", synth.sfm_database(96, 2000, 2028, share_frac=0.6, window=400), synth.all_pairs(96)),
     ("400 img x 2000 sparse, 8192 pairs", synth.sfm_database(400, 2000, 2027, share_frac=0.4, window=8), synth.all_pairs(400)[:8192]),
     ("400 img x 2000 sparse, 2048 pairs", synth.sfm_database(400, 2000, 2027, share_frac=0.4, window=8), synth.all_pairs(400)[:2048]),
+    ("200 img x 478 uniform, 19800 pairs", synth.sfm_database(200, 478, 2025, share_frac=0.5, window=12),
+     synth.all_pairs(200, np.repeat(np.arange(100), 2))),
+    ("200 img x 512 uniform, 19800 pairs", synth.sfm_database(200, 512, 2024, share_frac=0.5, window=12),
+     synth.all_pairs(200, np.repeat(np.arange(100), 2))),
     ("40 img x 500, 780 pairs", synth.sfm_database(40, 500, 2026, share_frac=0.5, window=12), synth.all_pairs(40)),
 ]
 for title, (db, off), pairs in DATASETS:
@@ -31,7 +35,7 @@ for title, (db, off), pairs in DATASETS:
     out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     m.set_profiling(True)
     ref = None
-    for name, v in (("default", 0), ("adaptive R8", 8), ("adaptive R8 4-wave WG", 0x1000008), ("fixed R8", 0x40008), ("fixed R4", 4), ("fixed R2", 2), ("fixed R1", 1)):
+    for name, v in (("default", 0), ("rmax 4", 0x40000008), ("rmax 2", 0x20000008), ("rmax 1", 0x10000008), ("fixed R8", 0x40008), ("fixed R4", 4), ("fixed R2", 2), ("fixed R1", 1)):
         m.set_variant(v)
         best = 1e9
         for _ in range(5):

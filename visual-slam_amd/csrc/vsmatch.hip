@@ -118,8 +118,11 @@ struct vsm_ctx {
   DevBuf d_img_off;
   std::vector<u32> img_off;
   u32 max_n = 0;
-  u32 max_tiles[2] = {0, 0};  // most adaptive tiles any image of the database needs, for rmax = 8, 4
-  bool uniform_tiles[2] = {false, false};  // ... and every image needs exactly that many
+  // per full-tile size rmax = 8, 4, 2, 1 (index 0..3): most adaptive tiles any image of the
+  // database needs, whether every image needs exactly that many, and the mean over images
+  u32 max_tiles[4] = {0, 0, 0, 0};
+  bool uniform_tiles[4] = {false, false, false, false};
+  double avg_tiles[4] = {0, 0, 0, 0};
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
@@ -240,7 +243,8 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
 // Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
 // query per lane and the train range split over grid.y so that all 256 CUs work.
 ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u32* exact_max_tiles = nullptr,
-                       const bool* uniform_tiles = nullptr) {
+                       const bool* uniform_tiles = nullptr, const double* avg_tiles = nullptr,
+                       u64 jobs_per_launch = 0) {
   ScanShape s;
   // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
   // override, bit 17 = integer-key tracking everywhere
@@ -257,7 +261,21 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   s.adaptive = s.R == 8 && !(variant & 0x40000);
   // bits 19 / 24: the earlier forms (512-query tiles without the skip test; 4-wave workgroups)
   s.rmax = (variant & (0x80000 | 0x1000000)) ? 8 : 4;
-  const int ri = s.rmax == 8 ? 0 : 1;  // index into the per-database tile statistics
+  if (s.adaptive && s.rmax == 4) {
+    // Shorter waves for smaller batches: keep >= ~16 rounds of the 8192 resident waves so the
+    // tail of the launch stays small (tools/ragged_probe.py: at euroc_V1's image sizes 64-query
+    // tiles beat 256-query ones by 10 %); low nibble of byte 3 of the knob forces rmax.
+    const u64 ls = std::max<u64>(1, (max_nt + FKEY_MAX_SET - 1) / FKEY_MAX_SET);
+    auto waves_at = [&](int rmax) {
+      const int ri = rmax == 8 ? 0 : rmax == 4 ? 1 : rmax == 2 ? 2 : 3;
+      const double per_job = avg_tiles ? avg_tiles[ri] : (double)adaptive_tiles(max_nq, (u32)rmax);
+      return (double)(jobs_per_launch ? jobs_per_launch : n_jobs) * per_job * (double)ls;
+    };
+    while (s.rmax > 1 && waves_at(s.rmax) < 131072.0) s.rmax /= 2;
+    const int force = (variant >> 28) & 0x7;
+    if (force == 1 || force == 2 || force == 4) s.rmax = force;
+  }
+  const int ri = s.rmax == 8 ? 0 : s.rmax == 4 ? 1 : s.rmax == 2 ? 2 : 3;  // index into the tile statistics
   const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles[ri] : adaptive_tiles_bound(max_nq, (u32)s.rmax))
                                : (max_nq + tq - 1) / tq;
   s.tiles = std::max(1u, tiles);
@@ -321,11 +339,17 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW, RR>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
                      sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
     if (fill == 2) {  // integer keys (a split scans more than 32768 train descriptors)
-      if (sh.rmax == 4) VSM_LAUNCH_A(2, 1, 4);
-      else if (w1) VSM_LAUNCH_A(2, 1, 8);
-      else VSM_LAUNCH_A(2, 4, 8);
+      if (sh.rmax == 8 && !w1) VSM_LAUNCH_A(2, 4, 8);
+      else if (sh.rmax == 8) VSM_LAUNCH_A(2, 1, 8);
+      else if (sh.rmax == 4) VSM_LAUNCH_A(2, 1, 4);
+      else if (sh.rmax == 2) VSM_LAUNCH_A(2, 1, 2);
+      else VSM_LAUNCH_A(2, 1, 1);
     } else if (sh.rmax == 4) {
       VSM_LAUNCH_A(8, 1, 4);  // shipped: 256-query tiles, FILL 8, one-wave workgroups
+    } else if (sh.rmax == 2) {
+      VSM_LAUNCH_A(8, 1, 2);
+    } else if (sh.rmax == 1) {
+      VSM_LAUNCH_A(8, 1, 1);
     } else if (w1) {
       VSM_LAUNCH_A(7, 1, 8);
     } else {
@@ -376,7 +400,9 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   }
   const u32 stride = std::max(64u, round_up(max_n, 64));
   const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : nullptr,
-                                    d_desc == c->db ? c->uniform_tiles : nullptr);
+                                    d_desc == c->db ? c->uniform_tiles : nullptr,
+                                    d_desc == c->db ? c->avg_tiles : nullptr,
+                                    std::min<u64>(n_pairs, 32768));  // forward jobs of one chunk
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
@@ -462,14 +488,16 @@ int check_ctx(vsm_ctx* c) {
 int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
   if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
   if (n_img >= 0xffffffffull) return fail(VSM_ERR_INVALID, "too many images");
-  u32 max_n = 0, max_tiles[2] = {0, 0}, min_tiles[2] = {0xffffffffu, 0xffffffffu};
+  u32 max_n = 0, max_tiles[4] = {0, 0, 0, 0}, min_tiles[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  double sum_tiles[4] = {0, 0, 0, 0};
   for (size_t i = 0; i < n_img; i++) {
     if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
     max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
-    for (int ri = 0; ri < 2; ri++) {
-      const u32 tl = adaptive_tiles(offsets[i + 1] - offsets[i], ri == 0 ? 8u : 4u);
+    for (int ri = 0; ri < 4; ri++) {
+      const u32 tl = adaptive_tiles(offsets[i + 1] - offsets[i], 8u >> ri);
       max_tiles[ri] = std::max(max_tiles[ri], tl);
       min_tiles[ri] = std::min(min_tiles[ri], tl);
+      sum_tiles[ri] += tl;
     }
   }
   if (max_n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "image with %u descriptors exceeds VSM_MAX_SET", max_n);
@@ -479,9 +507,10 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->img_off.assign(offsets, offsets + n_img + 1);
   c->max_n = max_n;
-  for (int ri = 0; ri < 2; ri++) {
+  for (int ri = 0; ri < 4; ri++) {
     c->max_tiles[ri] = max_tiles[ri];
     c->uniform_tiles[ri] = n_img > 0 && min_tiles[ri] == max_tiles[ri];
+    c->avg_tiles[ri] = n_img ? sum_tiles[ri] / (double)n_img : 0.0;
   }
   c->db = d_desc;
   return VSM_OK;
