@@ -101,3 +101,13 @@ def test_cpp_shim_detect_and_describe(tmp_path):
     desc.tofile(str(tmp_path / "desc.bin"))
     r = subprocess.run([exe, str(tmp_path), "detect"], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_repeated_detection_is_bit_identical(m):
+    """Race check: candidate compaction uses an atomic counter (arbitrary order) and the device
+    rank sort must undo it -- 20 runs, identical corners, angles and descriptors."""
+    img = np.random.default_rng(11).integers(0, 256, (480, 752)).astype(np.uint8)
+    ref = m.detect_and_describe(img, 1500, True)
+    for _ in range(20):
+        got = m.detect_and_describe(img, 1500, True)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))

@@ -283,3 +283,18 @@ def test_fuzz_random_shapes_and_parameters(m):
         offs, lists = m.match_pairs(pairs, thr, ratio)
         for k in range(0, 200, 3):
             assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], o.match(sets[2 * k], sets[2 * k + 1], thr, ratio)), k
+
+
+def test_repeated_runs_are_bit_identical(m):
+    """Race check: the same batch 25 times over (ragged database, pruned backward pass, atomics in
+    nominate_kernel) must give byte-identical offsets and lists every time."""
+    rng = np.random.default_rng(9)
+    sizes = rng.integers(100, 1400, size=60)
+    db, off = cases.synth.sfm_database(60, sizes, seed=91, share_frac=0.5, window=10)
+    pairs = cases.synth.all_pairs(60)
+    m.db_upload(db, off)
+    o0, l0 = m.match_pairs(pairs, 70, 1.2)
+    assert len(l0) > 5000
+    for _ in range(25):
+        o, l = m.match_pairs(pairs, 70, 1.2)
+        assert np.array_equal(o, o0) and np.array_equal(l, l0)
