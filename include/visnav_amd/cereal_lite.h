@@ -1,0 +1,193 @@
+// cereal_lite.h -- the reference's cached files without cereal.
+//
+// Reads `corners.cereal` and writes `matches.cereal`, the cereal BinaryOutputArchive files of
+// src/sfm.cpp:1203-1211 (feature_corners) and :1262-1270 / :1342-1350 (feature_matches), for
+// hosts that want the GPU matcher on a cached pipeline without linking cereal, Eigen or TBB.
+// Wire format (cereal 1.x, native little-endian; /root/reference/include/visnav/
+// serialization.h:176-205): size tags are uint64; a map is size + (key, value)*; FrameCamId =
+// int64 frame_id + uint64 cam_id; KeypointsData = corners (size + x, y doubles), corner_angles
+// (size + doubles), corner_descriptors (size + [uint8 type = 3 (bits) + 32 bytes, bit i at byte
+// i/8, mask 0x80 >> i%8]); MatchData = T_i_j (px py pz qx qy qz qw doubles), inliers, matches
+// (size + (int32, int32)*).  The Python twin is visual-slam_amd/cereal_io.py; both are pinned by
+// a byte-identical re-serialisation of the reference's test/ex4_test_data/
+// map_localize_camera.cereal (tests/test_cereal_io.py).
+#pragma once
+
+#include <array>
+#include <bitset>
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace visnav {
+namespace cereal_lite {
+
+struct FrameCamId {
+  int64_t frame_id = 0;
+  uint64_t cam_id = 0;
+  bool operator==(const FrameCamId& o) const { return frame_id == o.frame_id && cam_id == o.cam_id; }
+};
+
+struct KeypointsData {  // common_types.h:112-122
+  std::vector<std::array<double, 2>> corners;
+  std::vector<double> corner_angles;
+  std::vector<std::bitset<256>> corner_descriptors;
+};
+
+struct MatchData {  // common_types.h:128-138
+  std::array<double, 7> T_i_j{{0, 0, 0, 0, 0, 0, 1}};  // px py pz qx qy qz qw
+  std::vector<std::pair<int, int>> matches, inliers;
+};
+
+using Corners = std::vector<std::pair<FrameCamId, KeypointsData>>;                      // file order
+using Matches = std::vector<std::pair<std::pair<FrameCamId, FrameCamId>, MatchData>>;  // file order
+
+namespace detail {
+
+class Reader {
+ public:
+  explicit Reader(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cereal_lite: cannot open " + path);
+    buf_.assign((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  }
+  template <class T>
+  T get() {
+    T v;
+    take(&v, sizeof v);
+    return v;
+  }
+  uint64_t size() {
+    const uint64_t n = get<uint64_t>();
+    if (n > buf_.size()) throw std::runtime_error("cereal_lite: implausible size tag");
+    return n;
+  }
+  void take(void* dst, size_t n) {
+    if (pos_ + n > buf_.size()) throw std::runtime_error("cereal_lite: archive truncated");
+    std::memcpy(dst, buf_.data() + pos_, n);
+    pos_ += n;
+  }
+  bool at_end() const { return pos_ == buf_.size(); }
+
+ private:
+  std::vector<char> buf_;
+  size_t pos_ = 0;
+};
+
+inline uint8_t reverse_bits(uint8_t b) {
+  b = uint8_t((b & 0xF0) >> 4 | (b & 0x0F) << 4);
+  b = uint8_t((b & 0xCC) >> 2 | (b & 0x33) << 2);
+  return uint8_t((b & 0xAA) >> 1 | (b & 0x55) << 1);
+}
+
+// cereal's chunked `bits` payload <-> the in-memory image of std::bitset<256> (bit k = bit k%64
+// of word k/64, little-endian): same bytes with the bits of every byte reversed.
+inline std::bitset<256> bits_from_payload(const uint8_t* p) {
+  static_assert(sizeof(std::bitset<256>) == 32, "std::bitset<256> must be four packed 64-bit words");
+  uint8_t raw[32];
+  for (int i = 0; i < 32; i++) raw[i] = reverse_bits(p[i]);
+  std::bitset<256> b;
+  std::memcpy(static_cast<void*>(&b), raw, 32);
+  return b;
+}
+inline void payload_from_bits(const std::bitset<256>& b, uint8_t* p) {
+  uint8_t raw[32];
+  std::memcpy(raw, static_cast<const void*>(&b), 32);
+  for (int i = 0; i < 32; i++) p[i] = reverse_bits(raw[i]);
+}
+
+inline FrameCamId read_fcid(Reader& r) {
+  FrameCamId f;
+  f.frame_id = r.get<int64_t>();
+  f.cam_id = r.get<uint64_t>();
+  return f;
+}
+
+template <class T>
+void put(std::vector<char>& out, const T& v) {
+  const char* p = reinterpret_cast<const char*>(&v);
+  out.insert(out.end(), p, p + sizeof v);
+}
+
+inline void put_pairs(std::vector<char>& out, const std::vector<std::pair<int, int>>& v) {
+  put<uint64_t>(out, v.size());
+  for (const auto& p : v) {
+    put<int32_t>(out, p.first);
+    put<int32_t>(out, p.second);
+  }
+}
+
+}  // namespace detail
+
+// `corners.cereal` (src/sfm.cpp:1203-1211): every (FrameCamId, KeypointsData) in file order.
+inline Corners read_corners(const std::string& path) {
+  detail::Reader r(path);
+  Corners out(r.size());
+  for (auto& item : out) {
+    item.first = detail::read_fcid(r);
+    KeypointsData& kd = item.second;
+    kd.corners.resize(r.size());
+    if (!kd.corners.empty()) r.take(kd.corners.data(), kd.corners.size() * 16);
+    kd.corner_angles.resize(r.size());
+    if (!kd.corner_angles.empty()) r.take(kd.corner_angles.data(), kd.corner_angles.size() * 8);
+    kd.corner_descriptors.resize(r.size());
+    for (auto& d : kd.corner_descriptors) {
+      uint8_t rec[33];
+      r.take(rec, 33);
+      if (rec[0] != 3) throw std::runtime_error("cereal_lite: bitset not stored as type::bits");
+      d = detail::bits_from_payload(rec + 1);
+    }
+  }
+  if (!r.at_end()) throw std::runtime_error("cereal_lite: trailing bytes after Corners in " + path);
+  return out;
+}
+
+// `matches.cereal` (src/sfm.cpp:1262-1270): every ((FrameCamId, FrameCamId), MatchData) in order.
+inline void write_matches(const std::string& path, const Matches& items) {
+  std::vector<char> out;
+  detail::put<uint64_t>(out, items.size());
+  for (const auto& it : items) {
+    detail::put<int64_t>(out, it.first.first.frame_id);
+    detail::put<uint64_t>(out, it.first.first.cam_id);
+    detail::put<int64_t>(out, it.first.second.frame_id);
+    detail::put<uint64_t>(out, it.first.second.cam_id);
+    for (double v : it.second.T_i_j) detail::put<double>(out, v);
+    detail::put_pairs(out, it.second.inliers);
+    detail::put_pairs(out, it.second.matches);
+  }
+  std::ofstream f(path, std::ios::binary);
+  if (!f || !f.write(out.data(), std::streamsize(out.size()))) throw std::runtime_error("cereal_lite: cannot write " + path);
+}
+
+inline void write_corners(const std::string& path, const Corners& items) {
+  std::vector<char> out;
+  detail::put<uint64_t>(out, items.size());
+  for (const auto& it : items) {
+    detail::put<int64_t>(out, it.first.frame_id);
+    detail::put<uint64_t>(out, it.first.cam_id);
+    const KeypointsData& kd = it.second;
+    detail::put<uint64_t>(out, kd.corners.size());
+    for (const auto& c : kd.corners) {
+      detail::put<double>(out, c[0]);
+      detail::put<double>(out, c[1]);
+    }
+    detail::put<uint64_t>(out, kd.corner_angles.size());
+    for (double a : kd.corner_angles) detail::put<double>(out, a);
+    detail::put<uint64_t>(out, kd.corner_descriptors.size());
+    for (const auto& d : kd.corner_descriptors) {
+      uint8_t rec[33];
+      rec[0] = 3;
+      detail::payload_from_bits(d, rec + 1);
+      out.insert(out.end(), reinterpret_cast<char*>(rec), reinterpret_cast<char*>(rec) + 33);
+    }
+  }
+  std::ofstream f(path, std::ios::binary);
+  if (!f || !f.write(out.data(), std::streamsize(out.size()))) throw std::runtime_error("cereal_lite: cannot write " + path);
+}
+
+}  // namespace cereal_lite
+}  // namespace visnav

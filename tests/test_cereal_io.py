@@ -110,3 +110,31 @@ def test_reference_json_fixtures_equal_committed_goldens():
     # our JSON writer reproduces the reference's file value for value
     with open(os.path.join(REF, "ex3_test_data/kd0.json")) as f:
         assert json.loads(cio.keypoints_to_json(kd0)) == json.load(f)
+
+
+def test_cpp_cereal_lite_agrees_with_python(tmp_path):
+    """include/visnav_amd/cereal_lite.h (C++, no cereal): reads a corners.cereal written here,
+    writes it back byte-identically, and its matches.cereal parses to what the rule says."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(cases.GOLDEN.rstrip("/")), "cpp", "cereal_lite_test")
+    if not os.path.exists(exe):
+        pytest.skip("run __graft_entry__.build() first")
+    m = _toy_map()
+    src, back, mout = (str(tmp_path / n) for n in ("corners.cereal", "corners_back.cereal", "matches.cereal"))
+    cio.save_corners_binary(src, m["corners"])
+    r = subprocess.run([exe, src, back, mout], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(src, "rb").read() == open(back, "rb").read()
+    got = cio.load_matches_binary(mout)
+    assert len(got) == len(m["corners"]) - 1
+    for i, ((f1, f2), md) in enumerate(got, start=1):
+        assert f1 == m["corners"][i][0] and f2 == m["corners"][i - 1][0]
+        d = m["corners"][i - 1][1]["corner_descriptors"]
+        want = [[k, int(sum(bin(int(w)).count("1") for w in d[k]))] for k in range(len(d))]
+        assert md["matches"].tolist() == want and md["inliers"].tolist() == want[:1]
+        assert np.array_equal(md["T_i_j"], cio.IDENTITY_SE3)
+    if os.path.isdir(REF):  # the corners section of the reference's own map file
+        ref = cio.load_map_binary(os.path.join(REF, "ex4_test_data/map_localize_camera.cereal"))["corners"]
+        cio.save_corners_binary(src, ref)
+        r = subprocess.run([exe, src, back, mout], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and open(src, "rb").read() == open(back, "rb").read()
