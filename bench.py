@@ -418,6 +418,26 @@ def main():
                         "(2500 synthetic projected landmarks); images from tests/golden/euroc_subset"}
         except (OSError, ImportError):
             pass
+        # next row N4 (parity unpinned): vocabulary-tree descent (bow_voc.h:57-92) of one image's 1500
+        # descriptors through a synthetic k = 10, L = 5 tree (111 111 nodes)
+        voc = synth.vocabulary(10, 5, a.seed + 7)
+        m.voc_upload(voc)
+        leaves = np.flatnonzero(np.diff(voc["child_off"].astype(np.int64)) == 0)
+        bd_ = voc["node_desc"][leaves[rng.integers(0, len(leaves), 1500)]] ^ synth.flip_masks(1500, a.seed + 8, 1, levels=(3, 4))
+        for _ in range(5):
+            bw = m.bow_words(bd_)
+        t = time.perf_counter()
+        for _ in range(50):
+            bw = m.bow_words(bd_)
+        blat = (time.perf_counter() - t) / 50
+        t = time.perf_counter()
+        for _ in range(5):
+            cw = _ob.port().bow_words(bd_, voc)
+        bcpu = (time.perf_counter() - t) / 5
+        extra["bow_words_1500_features_k10_L5"] = {
+            "latency_ms_host_to_host": blat * 1e3, "cpu_port_ms_1_thread": bcpu * 1e3,
+            "bit_exact_vs_cpu": bool(np.array_equal(bw[0], cw[0]) and np.array_equal(bw[1], cw[1])),
+            "note": "parity unpinned: the reference's vocabulary file is not in its checkout; synthetic tree"}
         # config 3 shape: 164 images (82 stereo frames) of 1200-1500 descriptors, the 13284
         # non-stereo pairs of sfm.cpp:1285-1290 in one batch
         sz = np.random.default_rng(3).integers(1200, 1501, size=164)

@@ -189,5 +189,47 @@ inline void write_corners(const std::string& path, const Corners& items) {
   if (!f || !f.write(out.data(), std::streamsize(out.size()))) throw std::runtime_error("cereal_lite: cannot write " + path);
 }
 
+// `ORBvoc.cereal` (BowVocabulary::save, include/visnav/bow_voc.h:133-144, 197-208), flattened as
+// vsm_voc_upload (include/vsmatch.h) takes it.  Word ids are re-assigned over the leaves in node
+// order, as BowVocabulary::createWords() does after loading (bow_voc.h:219-232).
+struct Vocabulary {
+  int k = 0, L = 0;
+  std::vector<uint64_t> node_desc;  // [n][4]
+  std::vector<uint32_t> child_off, child_idx, node_id, word_id;
+  std::vector<double> weight;
+  size_t size() const { return node_id.size(); }
+};
+
+inline Vocabulary read_vocabulary(const std::string& path) {
+  detail::Reader r(path);
+  Vocabulary v;
+  v.k = r.get<int32_t>();
+  v.L = r.get<int32_t>();
+  const uint64_t n = r.size();
+  v.node_desc.resize(n * 4);
+  v.child_off.assign(n + 1, 0);
+  v.node_id.resize(n);
+  v.word_id.assign(n, 0);
+  v.weight.resize(n);
+  uint32_t next_word = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    v.node_id[i] = r.get<uint32_t>();
+    v.weight[i] = r.get<double>();
+    const uint64_t nc = r.size();
+    for (uint64_t c = 0; c < nc; c++) v.child_idx.push_back(r.get<uint32_t>());
+    v.child_off[i + 1] = uint32_t(v.child_idx.size());
+    (void)r.get<uint32_t>();  // parent
+    uint8_t rec[33];
+    r.take(rec, 33);
+    if (rec[0] != 3) throw std::runtime_error("cereal_lite: bitset not stored as type::bits");
+    const std::bitset<256> b = detail::bits_from_payload(rec + 1);
+    std::memcpy(&v.node_desc[4 * i], static_cast<const void*>(&b), 32);
+    (void)r.get<uint32_t>();  // stored word_id, overwritten by createWords()
+    if (nc == 0) v.word_id[i] = next_word++;
+  }
+  if (!r.at_end()) throw std::runtime_error("cereal_lite: trailing bytes after BowVocabulary in " + path);
+  return v;
+}
+
 }  // namespace cereal_lite
 }  // namespace visnav

@@ -195,6 +195,26 @@ int vsm_detect_and_describe(vsm_ctx* ctx, const uint8_t* img, int width, int hei
                             double* angles_out, uint64_t* desc_out, size_t cap, size_t* out_count);
 
 /*
+ * Vocabulary tree of visnav::BowVocabulary (include/visnav/bow_voc.h:163-247), flattened:
+ * node n has children child_idx[child_off[n] .. child_off[n+1]) (Node::children), centroid
+ * node_desc[n][4] (Node::descriptor), Node::id node_id[n] and, as a leaf, word_id[n] /
+ * weight[n] (after createWords(), bow_voc.h:219-232).  Root = node 0.  HOST pointers, copied.
+ */
+int vsm_voc_upload(vsm_ctx* ctx, const uint64_t* node_desc, const uint32_t* child_off,
+                   const uint32_t* child_idx, const uint32_t* node_id, const uint32_t* word_id,
+                   const double* weight, size_t n_nodes);
+/*
+ * Replaces the per-feature loop of BowVocabulary::transform over transformFeatureToWord
+ * (bow_voc.h:57-92, 112-113; called from match_bow, src/sfm.cpp:1379): word id and weight of
+ * the leaf each descriptor descends to (children compared by Hamming distance, the first of
+ * equally close children wins).  The BoW vector itself (accumulation in feature order, L1
+ * normalisation, bow_voc.h:114-130) is a few hundred additions and stays on the host.
+ * VSM_ERR_INVALID where the reference's loop would not terminate (a node none of whose children
+ * is closer than 256).  Parity unpinned: the reference's vocabulary file is not in its checkout.
+ */
+int vsm_bow_words(vsm_ctx* ctx, const uint64_t* desc, size_t n, uint32_t* word_out, double* weight_out);
+
+/*
  * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of
  * the last batched/nn2 call, measured with HIP events on the context's stream,
  * how many launches that was and how many 256-bit comparisons they evaluated.

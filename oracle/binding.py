@@ -67,6 +67,11 @@ class _Matcher:
             self._mineig = getattr(lib, prefix + "_gftt_mineig")
             self._mineig.restype = C.c_int
             self._mineig.argtypes = [_u8p, C.c_int, C.c_int, C.c_size_t, C.POINTER(C.c_float)]
+        self._bow = None
+        if hasattr(lib, prefix + "_bow_words"):
+            self._bow = getattr(lib, prefix + "_bow_words")
+            self._bow.restype = C.c_int
+            self._bow.argtypes = [_u64p, C.c_size_t, _u64p, _u32p, _u32p, _u32p, _u32p, _f64p, _u32p, _f64p]
         self._lm = None
         if hasattr(lib, prefix + "_match_landmarks"):
             self._lm = getattr(lib, prefix + "_match_landmarks")
@@ -129,6 +134,26 @@ class _Matcher:
         assert n <= cap
         return out[:n].copy()
 
+
+    def bow_words(self, desc, voc):
+        """BowVocabulary::transformFeatureToWord for every descriptor -> (word uint32[n],
+        weight f64[n]); `voc` = dict of flattened tree arrays (visual-slam_amd/synth.vocabulary).
+        Raises ValueError where the reference's loop would not terminate.  Port only."""
+        desc = _as_desc(desc)
+        n = len(desc)
+        word = np.zeros(n, dtype=np.uint32)
+        weight = np.zeros(n, dtype=np.float64)
+        nd = _as_desc(voc["node_desc"])
+        arr = {k: np.ascontiguousarray(voc[k], dtype=np.uint32) for k in ("child_off", "child_idx", "node_id", "word_id")}
+        ci = arr["child_idx"] if len(arr["child_idx"]) else np.zeros(1, np.uint32)
+        w = np.ascontiguousarray(voc["weight"], dtype=np.float64)
+        rc = self._bow(desc.ctypes.data_as(_u64p), n, nd.ctypes.data_as(_u64p), arr["child_off"].ctypes.data_as(_u32p),
+                       ci.ctypes.data_as(_u32p), arr["node_id"].ctypes.data_as(_u32p),
+                       arr["word_id"].ctypes.data_as(_u32p), w.ctypes.data_as(_f64p), word.ctypes.data_as(_u32p),
+                       weight.ctypes.data_as(_f64p))
+        if rc != 0:
+            raise ValueError("the reference's tree walk does not terminate on this input")
+        return word, weight
 
     def gftt(self, img, max_corners=1500, quality=0.01, min_distance=8.0) -> np.ndarray:
         """cv::goodFeaturesToTrack -> float64[n, 2] (x, y) in detection order; port only."""

@@ -1,0 +1,45 @@
+// shim_bow_test.cpp -- BowVocabularyGpu (include/visnav_amd/bow_voc_gpu.h) on a synthetic
+// vocabulary file written by visual-slam_amd/cereal_io.py: loads it with cereal_lite, transforms
+// a feature set on the GPU and compares the BoW vector with the one Python computed.
+// usage: shim_bow_test <voc.cereal> <features.bin> <expected.bin (uint32 word, double value)*>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "visnav_amd/bow_voc_gpu.h"
+
+template <class T>
+static std::vector<T> raw(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  std::vector<char> all((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  std::vector<T> v(all.size() / sizeof(T));
+  std::memcpy((void*)v.data(), all.data(), v.size() * sizeof(T));
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc != 5) return 2;
+  try {
+    visnav::BowVocabularyGpu voc(argv[1]);
+    auto features = raw<std::bitset<256>>(argv[2]);
+    auto want_w = raw<uint32_t>(argv[3]);
+    auto want_v = raw<double>(argv[4]);
+    std::vector<std::pair<unsigned int, double>> bow;
+    voc.transform(features, bow);
+    if (bow.size() != want_w.size()) {
+      std::fprintf(stderr, "FAIL: %zu words, want %zu\n", bow.size(), want_w.size());
+      return 1;
+    }
+    for (size_t i = 0; i < bow.size(); i++)
+      if (bow[i].first != want_w[i] || bow[i].second != want_v[i]) {
+        std::fprintf(stderr, "FAIL: entry %zu\n", i);
+        return 1;
+      }
+    std::printf("bow shim ok: %zu nodes, %zu features -> %zu words\n", voc.size(), features.size(), bow.size());
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "FAIL: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

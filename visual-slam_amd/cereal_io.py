@@ -345,6 +345,61 @@ def dump_map_binary(m):
     return w.bytes()
 
 
+def load_vocabulary_binary(path):
+    """`ORBvoc.cereal` (BowVocabulary::save, bow_voc.h:133-144, 203-208): int32 m_k, int32 m_L,
+    then m_nodes = size + per node (uint32 id, double weight, children = size + uint32s,
+    uint32 parent, bitset<256> descriptor, uint32 word_id).  Word ids are re-assigned in node
+    order over the leaves, as createWords() does after loading (bow_voc.h:219-232).  Returns the
+    flattened arrays of vsm_voc_upload."""
+    r = BinaryReader(_read(path))
+    k, L = r.i32(), r.i32()
+    n = r.size()
+    node_id = np.zeros(n, np.uint32)
+    weight = np.zeros(n, np.float64)
+    parent = np.zeros(n, np.uint32)
+    raw = np.zeros((n, 32), np.uint8)
+    child_off = np.zeros(n + 1, np.uint32)
+    kids = []
+    for i in range(n):
+        node_id[i] = r.array("<u4", 1)[0]
+        weight[i] = r.f64()
+        c = r.array("<u4", r.size())
+        kids.append(c)
+        child_off[i + 1] = child_off[i] + len(c)
+        parent[i] = r.array("<u4", 1)[0]
+        rec = r.array("u1", 33)
+        if rec[0] != BITSET_TYPE_BITS:
+            raise ValueError("bitset<256> stored with a type other than `bits` in a binary archive")
+        raw[i] = rec[1:]
+        r.array("<u4", 1)  # stored word_id, overwritten by createWords()
+    _finish(r, "BowVocabulary", path)
+    is_leaf = np.diff(child_off.astype(np.int64)) == 0
+    word_id = np.zeros(n, np.uint32)
+    word_id[is_leaf] = np.arange(int(is_leaf.sum()), dtype=np.uint32)
+    return {"k": k, "L": L, "node_desc": pack_bits_msb_bytes(raw) if n else np.zeros((0, 4), np.uint64),
+            "child_off": child_off, "child_idx": np.concatenate(kids).astype(np.uint32) if n and child_off[-1] else np.zeros(0, np.uint32),
+            "node_id": node_id, "word_id": word_id, "weight": weight, "parent": parent}
+
+
+def save_vocabulary_binary(path, voc):
+    w = BinaryWriter()
+    w.parts.append(struct.pack("<ii", int(voc["k"]), int(voc["L"])))
+    n = len(voc["node_id"])
+    w.size(n)
+    payload = unpack_bits_msb_bytes(voc["node_desc"]) if n else np.zeros((0, 32), np.uint8)
+    off = np.asarray(voc["child_off"], dtype=np.int64)
+    for i in range(n):
+        w.parts.append(struct.pack("<Id", int(voc["node_id"][i]), float(voc["weight"][i])))
+        c = np.asarray(voc["child_idx"][off[i]:off[i + 1]], dtype="<u4")
+        w.size(len(c))
+        w.parts.append(c.tobytes())
+        w.parts.append(struct.pack("<IB", int(voc["parent"][i]), BITSET_TYPE_BITS))
+        w.parts.append(payload[i].tobytes())
+        w.parts.append(struct.pack("<I", int(voc["word_id"][i])))
+    with open(path, "wb") as f:
+        f.write(w.bytes())
+
+
 # ----------------------------------------------------------------------------
 # JSON archives (cereal::JSONOutputArchive: unnamed values are "value0", "value1", ...)
 

@@ -7,6 +7,7 @@
 #include "landmark_kernels.h"
 #include "orb_kernels.h"
 #include "gftt_kernels.h"
+#include "bow_kernels.h"
 
 #include <algorithm>
 #include <cmath>
@@ -126,6 +127,8 @@ struct vsm_ctx {
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
+  DevBuf voc;          // vocabulary tree (vsm_voc_upload)
+  size_t voc_nodes = 0, voc_off[6] = {0, 0, 0, 0, 0, 0};
   PinBuf pin, pin_image;
   // measurement
   bool profiling = false;
@@ -558,7 +561,7 @@ void vsm_destroy(vsm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist,
-                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt})
+                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc})
       b->release();
     c->pin.release();
     c->pin_image.release();
@@ -1136,6 +1139,82 @@ int vsm_orb_descriptors(vsm_ctx* c, const uint8_t* img, int width, int height, s
                         const double* corners_xy, const double* angles, size_t n, uint64_t* desc_out) {
   if (n && (!angles || !desc_out)) return fail(VSM_ERR_INVALID, "null angles or desc_out");
   return orb_impl(c, img, width, height, pitch, corners_xy, n, 1, angles, nullptr, desc_out);
+}
+
+int vsm_voc_upload(vsm_ctx* c, const uint64_t* node_desc, const uint32_t* child_off, const uint32_t* child_idx,
+                   const uint32_t* node_id, const uint32_t* word_id, const double* weight, size_t n_nodes) {
+  VSM_TRY(check_ctx(c));
+  if (n_nodes == 0 || n_nodes >= 0x7fffffffull) return fail(VSM_ERR_INVALID, "vocabulary needs 1 .. 2^31 nodes");
+  if (!node_desc || !child_off || !node_id || !word_id || !weight) return fail(VSM_ERR_INVALID, "null vocabulary array");
+  if (child_off[0] != 0) return fail(VSM_ERR_INVALID, "child_off[0] must be 0");
+  for (size_t i = 0; i < n_nodes; i++) {
+    if (child_off[i + 1] < child_off[i]) return fail(VSM_ERR_INVALID, "child_off not ascending at node %zu", i);
+    if (node_id[i] >= n_nodes) return fail(VSM_ERR_INVALID, "node_id[%zu] out of range", i);
+  }
+  const size_t n_child = child_off[n_nodes];
+  if (n_child && !child_idx) return fail(VSM_ERR_INVALID, "null child_idx");
+  for (size_t k = 0; k < n_child; k++)
+    if (child_idx[k] >= n_nodes) return fail(VSM_ERR_INVALID, "child_idx[%zu] out of range", k);
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t* o = c->voc_off;  // desc | child_off | child_idx | node_id | word_id | weight
+  o[0] = 0;
+  o[1] = o[0] + al(n_nodes * DESC_BYTES);
+  o[2] = o[1] + al((n_nodes + 1) * 4);
+  o[3] = o[2] + al(std::max<size_t>(n_child, 1) * 4);
+  o[4] = o[3] + al(n_nodes * 4);
+  o[5] = o[4] + al(n_nodes * 4);
+  VSM_TRY(c->voc.reserve(o[5] + al(n_nodes * 8)));
+  char* d = (char*)c->voc.p;
+  HIP_TRY(hipMemcpyAsync(d + o[0], node_desc, n_nodes * DESC_BYTES, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + o[1], child_off, (n_nodes + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (n_child) HIP_TRY(hipMemcpyAsync(d + o[2], child_idx, n_child * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + o[3], node_id, n_nodes * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + o[4], word_id, n_nodes * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + o[5], weight, n_nodes * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->voc_nodes = n_nodes;
+  return VSM_OK;
+}
+
+int vsm_bow_words(vsm_ctx* c, const uint64_t* desc, size_t n, uint32_t* word_out, double* weight_out) {
+  VSM_TRY(check_ctx(c));
+  if (n == 0) return VSM_OK;
+  if (!desc || !word_out || !weight_out) return fail(VSM_ERR_INVALID, "null pointer");
+  if (n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "more than VSM_MAX_SET features");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (c->voc_nodes == 0) return fail(VSM_ERR_INVALID, "no vocabulary: call vsm_voc_upload first");
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_w = 0, o_v = al(n * 4), o_f = o_v + al(n * 8), down = o_f + 256;
+  VSM_TRY(c->pin.reserve(n * DESC_BYTES + down));
+  VSM_TRY(c->stage.reserve(n * DESC_BYTES));
+  VSM_TRY(c->w_out.reserve(down));
+  char* h = (char*)c->pin.p;
+  memcpy(h, desc, n * DESC_BYTES);
+  HIP_TRY(hipMemcpyAsync(c->stage.p, h, n * DESC_BYTES, hipMemcpyHostToDevice, c->stream));
+  char* dd = (char*)c->w_out.p;
+  HIP_TRY(hipMemsetAsync(dd + o_f, 0, 4, c->stream));
+  const char* v = (const char*)c->voc.p;
+  const size_t* o = c->voc_off;
+  hipLaunchKernelGGL(bow_words_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     (const u32x4*)c->stage.p, (u32)n, (const u32x4*)(v + o[0]), (const u32*)(v + o[1]),
+                     (const u32*)(v + o[2]), (const u32*)(v + o[3]), (const u32*)(v + o[4]),
+                     (const double*)(v + o[5]), (u32)c->voc_nodes, (u32*)(dd + o_w), (double*)(dd + o_v),
+                     (u32*)(dd + o_f));
+  HIP_TRY(hipGetLastError());
+  char* hd = h + n * DESC_BYTES;
+  HIP_TRY(hipMemcpyAsync(hd, dd, down, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  u32 flags;
+  memcpy(&flags, hd + o_f, 4);
+  if (flags & 1u)
+    return fail(VSM_ERR_INVALID, "a feature reaches a node none of whose children is closer than 256: "
+                                 "the reference's loop (bow_voc.h:77-88) does not terminate there");
+  memcpy(word_out, hd + o_w, n * 4);
+  memcpy(weight_out, hd + o_v, n * 8);
+  return VSM_OK;
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ SYMBOLS = (
     "vsm_match_landmarks",
     "vsm_orb_describe", "vsm_orb_angles", "vsm_orb_descriptors",
     "vsm_detect_keypoints", "vsm_good_features_to_track", "vsm_detect_and_describe",
+    "vsm_voc_upload", "vsm_bow_words",
 )
 
 
@@ -78,6 +79,8 @@ def lib():
                                                      _vp, _sz, C.POINTER(_sz)]
             L.vsm_detect_and_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, C.c_int, _vp, _vp, _vp,
                                                   _sz, C.POINTER(_sz)]
+            L.vsm_voc_upload.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]
+            L.vsm_bow_words.argtypes = [_vp, _vp, _sz, _vp, _vp]
             L.vsm_orb_angles.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp]
             L.vsm_orb_descriptors.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _vp, _sz, _vp]
             L.vsm_match_landmarks.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_double, C.c_int,
@@ -315,6 +318,33 @@ class Matcher:
                                          _ptr(ang), len(xy), _ptr(desc)))
         return desc
 
+    # -- bow_voc.h:57-131 ----------------------------------------------------------
+    def voc_upload(self, voc):
+        """`voc`: dict with node_desc uint64[n,4], child_off uint32[n+1], child_idx uint32[*],
+        node_id / word_id uint32[n], weight f64[n] (synth.vocabulary, cereal_io.load_vocabulary_binary)."""
+        nd = as_descriptors(voc["node_desc"])
+        a = {k: np.ascontiguousarray(voc[k], dtype=np.uint32) for k in ("child_off", "child_idx", "node_id", "word_id")}
+        w = np.ascontiguousarray(voc["weight"], dtype=np.float64)
+        n = len(nd)
+        if len(a["child_off"]) != n + 1 or len(a["node_id"]) != n or len(a["word_id"]) != n or len(w) != n:
+            raise ValueError("vocabulary arrays disagree in length")
+        _check(lib().vsm_voc_upload(self._h, _ptr(nd), _ptr(a["child_off"]), _ptr(a["child_idx"]), _ptr(a["node_id"]),
+                                    _ptr(a["word_id"]), _ptr(w), n))
+
+    def bow_words(self, desc):
+        """transformFeatureToWord for every descriptor -> (word uint32[n], weight f64[n])."""
+        d = as_descriptors(desc)
+        word = np.zeros(len(d), dtype=np.uint32)
+        weight = np.zeros(len(d), dtype=np.float64)
+        _check(lib().vsm_bow_words(self._h, _ptr(d), len(d), _ptr(word), _ptr(weight)))
+        return word, weight
+
+    def bow_transform(self, desc):
+        """BowVocabulary::transform (bow_voc.h:94-131): [(word_id, value)] in order of first
+        appearance, zero-weight words skipped, L1-normalised; words found on the GPU, the few
+        hundred double additions done here in the reference's order."""
+        return bow_vector(*self.bow_words(desc))
+
     # -- measurement ------------------------------------------------------------
     def set_profiling(self, on: bool):
         _check(lib().vsm_set_profiling(self._h, 1 if on else 0))
@@ -330,6 +360,21 @@ class Matcher:
         else:
             _check(lib().vsm_last_scan_stats_kind(self._h, int(kind), C.byref(ms), C.byref(n), C.byref(comps)))
         return {"scan_ms": ms.value, "launches": n.value, "comparisons": comps.value}
+
+
+def bow_vector(words, weights):
+    """bow_voc.h:107-130 given each feature's (word, weight)."""
+    order, acc, total = [], {}, 0.0
+    for w, v in zip(np.asarray(words).tolist(), np.asarray(weights, dtype=np.float64).tolist()):
+        if v == 0:
+            continue
+        total += v
+        if w in acc:
+            acc[w] += v
+        else:
+            acc[w] = v
+            order.append(w)
+    return [(w, acc[w] / total) for w in order]
 
 
 _default = threading.local()

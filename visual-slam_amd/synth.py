@@ -208,3 +208,43 @@ def landmark_frame(nk: int, n_proj: int, seed: int, width: float = 752.0, height
         proj_xy = np.floor(proj_xy)
     return (np.ascontiguousarray(kp_desc), np.ascontiguousarray(kp_xy), np.ascontiguousarray(proj_xy),
             obs_off, np.ascontiguousarray(obs_desc))
+
+
+def vocabulary(k: int, levels: int, seed: int, zero_weight_frac: float = 0.05, cluster_bits=(2, 3)):
+    """A synthetic k-ary vocabulary tree of `levels` levels below the root (the reference's
+    data/ORBvoc.cereal has k = 10, L = 6; that file is not in its checkout).  Children centroids
+    are noisy copies of their parent's, so the tree clusters descriptor space like a real
+    one; some leaves have weight 0 (bow_voc.h:114); nodes are stored parent-before-children.
+    Returns the flattened arrays of include/vsmatch.h (vsm_voc_upload) as a dict."""
+    n_nodes = sum(k ** l for l in range(levels + 1))
+    node_desc = np.zeros((n_nodes, 4), dtype=np.uint64)
+    child_off = np.zeros(n_nodes + 1, dtype=np.uint32)
+    child_idx = []
+    node_desc[0] = random_descriptors(1, seed, 40)[0]
+    first, nxt = 0, 1
+    for l in range(levels):
+        width = k ** l
+        kids = np.arange(nxt, nxt + width * k).reshape(width, k)
+        masks = flip_masks(width * k, seed, 50 + l, levels=cluster_bits).reshape(width, k, 4)
+        node_desc[kids] = node_desc[first:first + width, None, :] ^ masks
+        child_idx.append(kids.reshape(-1))
+        child_off[first + 1:first + width + 1] = child_off[first] + k * np.arange(1, width + 1)
+        first, nxt = first + width, nxt + width * k
+    child_off[first + 1:] = child_off[first]
+    child_idx = np.concatenate(child_idx).astype(np.uint32) if child_idx else np.zeros(0, np.uint32)
+    is_leaf = np.diff(child_off.astype(np.int64)) == 0
+    word_id = np.zeros(n_nodes, dtype=np.uint32)
+    word_id[is_leaf] = np.arange(int(is_leaf.sum()), dtype=np.uint32)  # createWords(), bow_voc.h:219-232
+    weight = np.zeros(n_nodes, dtype=np.float64)
+    u = _unit(seed, 60, (n_nodes,))
+    weight[is_leaf] = np.where(u[is_leaf] < zero_weight_frac, 0.0, 0.5 + 10.0 * _unit(seed, 61, (n_nodes,))[is_leaf])
+    return {"k": k, "L": levels, "node_desc": np.ascontiguousarray(node_desc), "child_off": child_off,
+            "child_idx": child_idx, "node_id": np.arange(n_nodes, dtype=np.uint32), "word_id": word_id,
+            "weight": weight, "parent": _parents(child_off, child_idx, n_nodes)}
+
+
+def _parents(child_off, child_idx, n_nodes):
+    parent = np.zeros(n_nodes, dtype=np.uint32)
+    counts = np.diff(child_off.astype(np.int64))
+    parent[child_idx] = np.repeat(np.arange(n_nodes, dtype=np.uint32), counts)
+    return parent
