@@ -105,7 +105,7 @@ struct PinBuf {
 constexpr size_t DESC_BYTES = 32;
 constexpr size_t SCRATCH_BUDGET = (size_t)2 << 30;  // scan results per chunk of pairs
 constexpr u32 TARGET_WAVES = 4096;                  // below this the train range is split
-constexpr u32 LONG_SCAN_WAVES = 98304;              // 16 x the 6144 resident waves of scan_kernel<4>
+constexpr u32 LONG_SCAN_WAVES = 98304;              // long scans are split until a launch has this many waves
 
 }  // namespace
 
@@ -242,7 +242,8 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
   return best;
 }
 
-// Queries per wave (64*R) and train splits.  Large batches: R = 4, no split.
+// Queries per wave (64*R), tile form and train splits.  Large batches: the adaptive kernel
+// (256-query tiles or smaller, one-wave workgroups), no split.
 // Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
 // query per lane and the train range split over grid.y so that all 256 CUs work.
 ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u32* exact_max_tiles = nullptr,
