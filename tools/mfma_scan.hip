@@ -1,0 +1,123 @@
+// tools/mfma_scan.hip -- the matrix-core scan (csrc/mfma_scan.h) against the popcount scan on the
+// same jobs: bitwise comparison of the scratch results and launch times.
+//   hipcc --offload-arch=gfx950 -O3 -I visual-slam_amd/csrc tools/mfma_scan.hip -o /tmp/mfma_scan
+//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "mfma_scan.h"
+using namespace vsm;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
+
+__device__ inline u32 mix(u32 x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// Every fourth descriptor index k holds the same base pattern in all images with a few bits
+// flipped per image (true matches, distance ~ 16); the others are independent random bits.
+__global__ void fill_db(u32* p, u32 n_img, u32 N) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)n_img * N * 8) return;
+  const u32 w = i & 7, k = (i >> 3) % N, img = (i >> 3) / N;
+  const u32 r = mix((u32)i * 2654435761u + 12345u);
+  if (k % 4 == 0) {
+    const u32 base = mix(k * 8 + w + 777u);
+    const u32 noise = r & mix(r + 1) & mix(r + 2) & mix(r + 3) & mix(r + 4);
+    p[i] = base ^ noise ^ (img & 0);
+  } else {
+    p[i] = r;
+  }
+}
+
+int main(int argc, char** argv) {
+  const u32 n_img = 512, N = argc > 1 ? atoi(argv[1]) : 2000, P = argc > 2 ? atoi(argv[2]) : 4096;
+  const u32 d_lim = argc > 3 ? atoi(argv[3]) : 256;
+  u32* db;
+  CK(hipMalloc(&db, (size_t)n_img * N * 32));
+  fill_db<<<(u32)(((size_t)n_img * N * 8 + 255) / 256), 256>>>(db, n_img, N);
+  const u32 stride = (N + 63) / 64 * 64;
+  std::vector<Job> jobs(2 * P);
+  for (u32 p = 0; p < P; p++) {
+    u32 i = (p * 7 + 1) % n_img, j = (p * 13 + 5) % n_img;
+    jobs[2 * p] = {i * N, N, j * N, N, p * 2 * stride, NO_QLIST, 0, 0};
+    jobs[2 * p + 1] = {j * N, N, i * N, N, p * 2 * stride + stride, NO_QLIST, 0, 0};
+  }
+  Job* d_jobs;
+  CK(hipMalloc(&d_jobs, jobs.size() * sizeof(Job)));
+  CK(hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(Job), hipMemcpyHostToDevice));
+  const size_t n_scr = (size_t)P * 2 * stride;
+  uint2 *scr_ref, *scr;
+  CK(hipMalloc(&scr_ref, n_scr * sizeof(uint2)));
+  CK(hipMalloc(&scr, n_scr * sizeof(uint2)));
+  std::vector<uint2> h_ref(n_scr), h(n_scr);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const double comps = 2.0 * P * (double)N * N;
+  const u32 n_jobs = 2 * P;
+
+  // reference: the shipped popcount kernel
+  float t_ref = 1e30f;
+  for (int rep = 0; rep < 3; rep++) {
+    CK(hipMemset(scr_ref, 0xff, n_scr * sizeof(uint2)));
+    const u32 tiles = adaptive_tiles(N, 4), groups = (n_jobs + 7) / 8;
+    CK(hipEventRecord(e0));
+    scan_kernel_adaptive<8, 1, 4><<<dim3(groups * 8 * tiles), dim3(64)>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr_ref, nullptr, tiles);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float t; CK(hipEventElapsedTime(&t, e0, e1));
+    t_ref = std::min(t_ref, t);
+  }
+  CK(hipMemcpy(h_ref.data(), scr_ref, n_scr * sizeof(uint2), hipMemcpyDeviceToHost));
+  printf("N=%u pairs=%u d_lim=%u comps/launch=%.3e\n", N, P, d_lim, comps);
+  printf("%-28s %8.3f ms %9.1f Gcomp/s\n", "popcount adaptive<8,1,4>", t_ref, comps / (t_ref * 1e-3) / 1e9);
+
+  struct V { const char* name; int fmt, nb; };
+  const V vs[] = {{"mfma fp4 NB8", 4, 8}, {"mfma fp4 NB4", 4, 4}, {"mfma fp8 NB8", 0, 8}, {"mfma fp8 NB4", 0, 4}};
+  for (const V& v : vs) {
+    float tm = 1e30f;
+    const u32 tiles = adaptive_tiles(N, v.nb / 2), groups = (n_jobs + 7) / 8;
+    for (int rep = 0; rep < 3; rep++) {
+      CK(hipMemset(scr, 0xff, n_scr * sizeof(uint2)));
+      CK(hipEventRecord(e0));
+      const dim3 g(groups * 8 * tiles), blk(64);
+#define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
+      if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS);
+      else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS);
+      else if (v.nb == 8) mfma_scan_kernel<0, 8><<<g, blk>>>(ARGS);
+      else mfma_scan_kernel<0, 4><<<g, blk>>>(ARGS);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float t; CK(hipEventElapsedTime(&t, e0, e1));
+      tm = std::min(tm, t);
+    }
+    CK(hipMemcpy(h.data(), scr, n_scr * sizeof(uint2), hipMemcpyDeviceToHost));
+    // expected result under the limit: keys of distance >= d_lim are replaced by the start key
+    size_t bad = 0, first_bad = 0, cand = 0;
+    for (size_t i = 0; i < n_scr; i++) {
+      uint2 e = h_ref[i];
+      if (e.x == 0xffffffffu && e.y == 0xffffffffu) {  // never written
+        if (h[i].x != 0xffffffffu || h[i].y != 0xffffffffu) { if (!bad) first_bad = i; bad++; }
+        continue;
+      }
+      const u32 job = (u32)(i / stride);
+      const u32 t_off_rel = 0;  // float keys index from the start of the range; t0 = 0 here
+      (void)job; (void)t_off_rel;
+      const u32 sentinel = d_lim >= 256 ? KEY_INIT : (d_lim << IDX_BITS);
+      if ((e.x >> IDX_BITS) >= d_lim) e.x = sentinel;
+      if ((e.y >> IDX_BITS) >= d_lim) e.y = sentinel;
+      if ((e.x >> IDX_BITS) < d_lim) cand++;
+      if (e.x != h[i].x || e.y != h[i].y) { if (!bad) first_bad = i; bad++; }
+    }
+    printf("%-28s %8.3f ms %9.1f Gcomp/s  x%.2f  queries with a candidate %zu  %s", v.name, tm, comps / (tm * 1e-3) / 1e9,
+           t_ref / tm, cand, bad ? "MISMATCH" : "bit-exact");
+    if (bad) printf(" (%zu entries, first %zu: want %08x %08x got %08x %08x)", bad, first_bad, h_ref[first_bad].x, h_ref[first_bad].y, h[first_bad].x, h[first_bad].y);
+    printf("\n");
+  }
+  return 0;
+}
