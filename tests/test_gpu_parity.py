@@ -48,12 +48,14 @@ def test_pair_matches_recorded_reference(m, name):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
-                                     0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008, 0x1000008, 0x1020008])
+                                     0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008, 0x1000008, 0x1020008,
+                                     0x0308, 0x2000008, 0x2000308, 0x10000008, 0x20000008, 0x40000008, 0x12000008, 0x20000208])
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
     tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
-    decomposition (256-query tiles, skip test) unless bit 18 is set; bits 19 / 24 select its
-    earlier forms: 512-query tiles without the skip test, one-wave / 4-wave workgroups) gives
+    decomposition unless bit 18 is set -- on the matrix cores (mfma_scan.h) unless bit 25 asks
+    for the popcount scan; bits 28-30 force the tile size; bits 19 / 24 select earlier popcount
+    forms: 512-query tiles without the skip test, one-wave / 4-wave workgroups) gives
     the same list."""
     m.set_variant(variant)
     try:
@@ -65,8 +67,26 @@ def test_pair_all_kernel_shapes(m, variant):
         m.set_variant(0)
 
 
+@pytest.mark.parametrize("thr,ratio", [(70, 1.2), (256, 1.0), (300, 1.0), (257, 0.9), (50, 3.0), (100, 0.5), (1, 1.2),
+                                       (0, 1.2), (-5, 1.2), (70, 0.0), (70, -1.0), (70, 4.0), (200, 1.01), (70, float("nan")),
+                                       (128, 1.5), (255, 1.0)])
+def test_accept_limit_of_the_matrix_core_scan(m, thr, ratio):
+    """The matrix-core scan starts (best, second) at the smallest distance the accept test
+    cannot tell from anything larger (accept_limit, vsmatch.hip); whatever threshold and ratio
+    that limit is derived from, the list is the oracle's."""
+    for variant in (8, 0x10000008, 0x0308):
+        m.set_variant(variant)
+        try:
+            for (n1, n2, seed) in [(300, 777, 1), (1023, 1025, 2), (64, 33, 3), (5, 2000, 4)]:
+                d1, d2 = cases.synth.orb_like_pair(n1, n2, seed)
+                assert np.array_equal(m.match(d1, d2, thr, ratio), binding.port().match(d1, d2, thr, ratio)), \
+                    (variant, thr, ratio, n1, n2)
+        finally:
+            m.set_variant(0)
+
+
 def test_nn2_vs_oracle(m):
-    for variant in (0, 0x20000):
+    for variant in (0, 0x20000, 8, 0x2000008, 0x10000008):
         m.set_variant(variant)
         try:
             for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6),

@@ -54,21 +54,27 @@ __device__ __forceinline__ i32x8 expand_bits(u32 w) {
 
 template <int FMT>
 __device__ __forceinline__ f32x16 mfma_step(const i32x8 a, const i32x8 b, const f32x16 c) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, FMT, FMT, 0, 0, 0, 0);
+  // block scales (e8m0): A x 2^0, B x 2^-7, so that a product is +-1/128 and the accumulator,
+  // started at the inline constant 4.0, stays in [2, 6]
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, FMT, FMT, 0, 0x7f7f7f7f, 0, 0x78787878);
 }
 
-__device__ __forceinline__ float min3f(float a, float b, float c) {
-  float r;
-  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// The accumulators start at 4.0 (an inline constant: any other start value costs 16 register
+// copies per MFMA chain) and the products are scaled by 1/128, so every D' = 4 + (2 d - 256) / 128
+// = 2 + d / 64 is a positive float and its bit pattern orders like the value: the minimum tree
+// runs on v_min3_i32 (the compiler's own instruction, so it also places the wait states an MFMA
+// result needs before a VALU read; an f32 minimum would add a canonicalising v_max_f32 per input).
+constexpr float MFMA_BIAS = 4.0f;
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
-constexpr float MFMA_KEY_BASE = 12582912.0f;  // 2^23 + 128 * 32768: key = D * 16384 + this + j
+// float key (vsmatch_kernels.h FILL 5) = 2^23 + d * 32768 + j = D' * MFMA_KEY_SCALE + MFMA_KEY_BASE + j
+constexpr float MFMA_KEY_SCALE = 64.0f * 32768.0f;
+constexpr float MFMA_KEY_BASE = 8388608.0f - 2.0f * MFMA_KEY_SCALE;
 
-// the largest D = 2 d - 256 that can still change a lane whose second best key is `second`
-__device__ __forceinline__ float limit_of(float second) {
+// the largest D' that can still change a lane whose second best key is `second`, as its bit pattern
+__device__ __forceinline__ int limit_of(float second) {
   const float x = (second - 8388608.0f) * (1.0f / 32768.0f);  // d + j / 32768, exact
-  return 2.0f * (ceilf(x) - 1.0f) - 256.0f;
+  return __float_as_int(2.0f + (ceilf(x) - 1.0f) * (1.0f / 64.0f));
 }
 
 // One tile = 32 * NB queries of a job (lane l: column l & 31 of each block of 32, half l >> 5 of
@@ -95,7 +101,8 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
     B[b][3] = expand_bits<FMT>(~w.w);
   }
   const float init = 8388608.0f + 32768.0f * (float)d_lim;
-  float best[NB], second[NB], lim[NB];
+  float best[NB], second[NB];
+  int lim[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     best[b] = second[b] = init;
@@ -105,23 +112,44 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
   if (t1 > t0) {
     const u32x4* tr = tbase + 2 * (size_t)job.t_off + h;
     const u32 last = t1 - 1;
-    u32x4 wn = tr[2 * (size_t)min(t0 + c, last)];
+    const float z = MFMA_BIAS;
+    const f32x16 zero = {z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
+    // Software pipeline over (32 train rows, query block) steps: the four MFMAs of the next step
+    // are issued before the minimum tree of the current one, so the tree runs in their shadow.
+    u32x4 w = tr[2 * (size_t)min(t0 + c, last)];
+    u32x4 wn = tr[2 * (size_t)min(t0 + 32 + c, last)];
+    i32x8 A[4];
+    A[0] = expand_bits<FMT>(w.x);
+    A[1] = expand_bits<FMT>(w.y);
+    A[2] = expand_bits<FMT>(w.z);
+    A[3] = expand_bits<FMT>(w.w);
+    f32x16 D = zero;
+#pragma unroll
+    for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[0][m], D);
     for (u32 j = t0; j < t1; j += 32) {
-      const u32x4 w = wn;
-      wn = tr[2 * (size_t)min(j + 32 + c, last)];
-      i32x8 A[4];
-      A[0] = expand_bits<FMT>(w.x);
-      A[1] = expand_bits<FMT>(w.y);
-      A[2] = expand_bits<FMT>(w.z);
-      A[3] = expand_bits<FMT>(w.w);
 #pragma unroll
       for (int b = 0; b < NB; b++) {
-        f32x16 D = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f32x16 Dn = zero;
+        if (b + 1 < NB) {
 #pragma unroll
-        for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[b][m], D);
-        const float m0 = min3f(D[0], D[1], D[2]), m1 = min3f(D[3], D[4], D[5]), m2 = min3f(D[6], D[7], D[8]);
-        const float m3 = min3f(D[9], D[10], D[11]), m4 = min3f(D[12], D[13], D[14]);
-        const float lo = min3f(min3f(m0, m1, m2), min3f(m3, m4, D[15]), 1e30f);
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[b + 1][m], Dn);
+        } else {
+          // next 32 train rows (past the end: the clamped last row again, result unused)
+          w = wn;
+          wn = tr[2 * (size_t)min(j + 64 + c, last)];
+          A[0] = expand_bits<FMT>(w.x);
+          A[1] = expand_bits<FMT>(w.y);
+          A[2] = expand_bits<FMT>(w.z);
+          A[3] = expand_bits<FMT>(w.w);
+#pragma unroll
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[0][m], Dn);
+        }
+        asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the test below (and their result in VGPRs)
+#define DI(k) __float_as_int(D[k])
+        const int m0 = min3i(DI(0), DI(1), DI(2)), m1 = min3i(DI(3), DI(4), DI(5)), m2 = min3i(DI(6), DI(7), DI(8));
+        const int m3 = min3i(DI(9), DI(10), DI(11)), m4 = min3i(DI(12), DI(13), DI(14));
+        const int lo = min(min3i(m0, m1, m2), min3i(m3, m4, DI(15)));
+#undef DI
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(lo <= lim[b]) != 0, 0)) {
           // slow path: some lane has a candidate.  Row of element i: (i & 3) + 8 (i >> 2) + 4 h.
           const float cj = MFMA_KEY_BASE + (float)(j - t0 + 4 * h);
@@ -129,7 +157,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
 #pragma unroll
           for (int i = 0; i < 16; i++) {
             const u32 off = (u32)((i & 3) + 8 * (i >> 2));
-            float key = fmaf(D[i], 16384.0f, cj + (float)off);
+            float key = fmaf(D[i], MFMA_KEY_SCALE, cj + (float)off);
             key = (j + 4 * h + off < t1) ? key : 16777216.0f;
             ss = __builtin_amdgcn_fmed3f(bb, key, ss);
             bb = fminf(bb, key);
@@ -138,6 +166,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
           second[b] = ss;
           lim[b] = limit_of(ss);
         }
+        D = Dn;
       }
     }
   }

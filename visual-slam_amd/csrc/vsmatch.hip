@@ -4,6 +4,7 @@
 // and its batched call pattern (src/sfm.cpp:1295-1321).  No CPU fallback: every
 // entry point needs a HIP device and fails with VSM_ERR_HIP otherwise.
 #include "vsmatch_kernels.h"
+#include "mfma_scan.h"
 #include "landmark_kernels.h"
 #include "orb_kernels.h"
 #include "gftt_kernels.h"
@@ -171,6 +172,16 @@ void make_accept(int threshold, double dist_2_best, AcceptParams* prm) {
   prm->min_second[257] = 257;
 }
 
+// Smallest distance L such that the accept test (keypoints.h:295-296) cannot tell a best or
+// second best distance >= L from L itself: a best >= threshold is rejected whatever it is, and a
+// second best >= every min_second[b], b < threshold, passes whatever it is.  The matrix-core scan
+// starts its (best, second) at L and so skips every block of distances that are all >= L.
+u32 accept_limit(const AcceptParams& prm) {
+  int lim = std::max(prm.threshold, 1);
+  for (int b = 0; b < std::min(prm.threshold, 256); b++) lim = std::max(lim, (int)prm.min_second[b]);
+  return (u32)std::min(lim, 256);
+}
+
 // Radius gate of find_matches_landmarks (vo_utils.h:136-138): `norm > r` with norm =
 // sqrt(squared) correctly rounded is, by monotonicity of sqrt, `squared > T` with T the
 // largest double whose square root is <= r.  NaN r: nothing is ever skipped (T = +inf);
@@ -231,6 +242,7 @@ struct ScanShape {
   u32 tiles;      // most tiles a job has (adaptive: grid of one-wave workgroups = n_jobs x tiles)
   bool uniform;   // every job has exactly `tiles` tiles (grouped block order, see the kernel)
   int rmax;       // adaptive: queries per lane of the full tiles (4 shipped, 8 with knob bits 19/24)
+  bool mfma;      // matrix-core scan (mfma_scan.h) instead of the popcount scan: adaptive + float keys
 };
 
 // Most tiles scan_kernel_adaptive can need for a job of at most max_nq queries (the tile
@@ -298,12 +310,14 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   if (vs) s.splits = (u32)vs;
   const u32 per = (max_nt + s.splits - 1) / s.splits;
   s.fkey = per <= FKEY_MAX_SET && !(variant & 0x20000);
+  // bit 25 of the experiment knob: the popcount scan everywhere (A/B runs, parity tests)
+  s.mfma = s.adaptive && s.fkey && s.rmax <= 4 && !(variant & 0x2000000);
   return s;
 }
 
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
-                const u32* d_qlist = nullptr) {
+                const u32* d_qlist = nullptr, u32 d_lim = 256) {
   const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
   const u64 blocks = n_jobs * sh.wgs_per_job;
@@ -342,7 +356,14 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #define VSM_LAUNCH_A(FF, WW, RR)                                                                     \
   hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW, RR>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
                      sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
-    if (fill == 2) {  // integer keys (a split scans more than 32768 train descriptors)
+#define VSM_LAUNCH_M(NN)                                                                               \
+  hipLaunchKernelGGL((mfma_scan_kernel<4, NN>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
+                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim)
+    if (sh.mfma && w1) {  // shipped: FP4 matrix-core scan, 32 * NN queries per wave
+      if (sh.rmax == 4) VSM_LAUNCH_M(8);
+      else if (sh.rmax == 2) VSM_LAUNCH_M(4);
+      else VSM_LAUNCH_M(2);
+    } else if (fill == 2) {  // integer keys (a split scans more than 32768 train descriptors)
       if (sh.rmax == 8 && !w1) VSM_LAUNCH_A(2, 4, 8);
       else if (sh.rmax == 8) VSM_LAUNCH_A(2, 1, 8);
       else if (sh.rmax == 4) VSM_LAUNCH_A(2, 1, 4);
@@ -360,6 +381,7 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
       VSM_LAUNCH_A(7, 4, 8);
     }
 #undef VSM_LAUNCH_A
+#undef VSM_LAUNCH_M
   } else
   // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
   switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
@@ -434,6 +456,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
   u32* d_counts = (u32*)c->counts.p;
+  const u32 d_lim = accept_limit(prm);
 
   for (u64 first = 0; first < n_pairs; first += chunk) {
     const u32 n = (u32)std::min<u64>(chunk, n_pairs - first);
@@ -442,14 +465,14 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        prune ? 1u : 2u);
     HIP_TRY(hipGetLastError());
     if (prune) {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0));
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
                          stride, (u32*)c->qlist.p, d_comps + 1);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
-                          (const u32*)c->qlist.p));
+                          (const u32*)c->qlist.p, d_lim));
     } else {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0));
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
     }
     if (sh.splits > 1) {
       const u32 n_entries = n * 2 * stride;
@@ -704,7 +727,7 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   const u32 split_stride = 2 * stride;
   VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
   VSM_TRY(launch_scan(c, c->stage.p, c->stage.p, d_jobs, 2, sh, split_stride, (uint2*)c->scratch.p,
-                      2ull * n1 * n2));
+                      2ull * n1 * n2, nullptr, accept_limit(prm)));
   u64* d_off = (u64*)c->w_out.p;
   int2* d_out = (int2*)((char*)c->w_out.p + 16);
   if (sh.splits > 1)
