@@ -37,17 +37,22 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Roofline denominator: 1 comparison = 8 v_xor_b32 + 8 v_bcnt_u32_b32 = 16
-# int32 VALU lane-ops.  SURVEY/BASELINE.md price the peak at 64 lanes/clk/CU (every VALU
-# instruction 4 cycles per wave64 per SIMD) = 39.32 T lane-ops/s, "to be confirmed with a
-# micro-benchmark".  The micro-benchmarks (tools/valu_rate2, profiles/r01/valu_rate2_*.txt)
-# measured 2.32 cycles for v_xor_b32 and 4.61 cycles for v_bcnt_u32_b32 (which cannot be
-# had cheaper in any instruction mix tried), so the irreducible 8 + 8 instructions cost
-# 8*2.32 + 8*4.61 = 55.4 cycles per SIMD per 64 comparisons: peak = 1024 SIMDs x 64 lanes x
-# 2.4 GHz / 55.4 x 16 lane-ops = 45.4 T lane-ops/s = 2.84 T comparisons/s.  That measured,
-# stricter figure is `peak`; the fraction of the nominal 39.32 T is reported beside it.
+# Roofline.  The shipped forward scan computes a 256-bit Hamming distance as a
+# dot product of +-1 FP4 codes on the matrix cores (csrc/mfma_scan.h): 256 multiply-adds = 512
+# FLOP per comparison, v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands = 2 * 32*32*64 FLOP in
+# 32 cycles per SIMD, so peak = 1024 SIMDs x 4096 FLOP/clk x 2.4 GHz = 10.07 PFLOP/s (the dense FP4
+# figure of MI355X_MICROARCH.md) = 19.66 T comparisons/s.
+# The popcount scan it replaced (v_xor_b32 + v_bcnt_u32_b32, still used for short jobs and the
+# pruned backward pass) is priced as before: 16 int32 VALU lane-ops per comparison; nominal peak
+# 64 lanes/clk/CU = 39.32 T lane-ops/s = 2.46 T comparisons/s; with the measured issue cycles
+# (tools/valu_rate2: 2.32 for v_xor, 4.61 for v_bcnt) 45.4 T lane-ops/s = 2.84 T comparisons/s.
+# The forward scan is reported against the MFMA peak (`frac`) and, beside it, as a multiple of
+# the popcount roofline SURVEY.md/BASELINE.md set as the target.
+FLOP_PER_COMP = 512
+F_MAX = 2.4e9
+PEAK_MFMA_TFLOPS = 1024 * (2 * 32 * 32 * 64 / 32) * F_MAX / 1e12  # 10066
 LANE_OPS_PER_COMP = 16
-CYC_XOR, CYC_BCNT, F_MAX = 2.32, 4.61, 2.4e9
+CYC_XOR, CYC_BCNT = 2.32, 4.61
 PEAK_TLANEOPS = 1024 * 64 * F_MAX / (8 * CYC_XOR + 8 * CYC_BCNT) * LANE_OPS_PER_COMP / 1e12
 NOMINAL_TLANEOPS = 256 * 64 * F_MAX / 1e12  # 39.32, BASELINE.md §4
 
@@ -260,17 +265,21 @@ def main():
     fwd, bwd = kinds
     scan_comps = fwd["comparisons"] + bwd["comparisons"]
     assert 0 < scan_comps <= comps_rank, (scan_comps, comps_rank)
-    achieved = fwd["comparisons"] * LANE_OPS_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
+    achieved = fwd["comparisons"] * FLOP_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
+    fwd_laneops = fwd["comparisons"] * LANE_OPS_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
     roofline = {
-        "bound": "valu", "kernel": "scan_kernel_adaptive<8,1,4> (forward scans, the dominant kernel: one-wave workgroups, 256-query tiles, float keys, skip test)",
-        "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlaneop/s", "frac": achieved / PEAK_TLANEOPS,
-        "frac_of_nominal_64_lanes_per_clk_peak": achieved / NOMINAL_TLANEOPS,
+        "bound": "mfma", "kernel": "mfma_scan_kernel<4,8> (forward scans, the dominant kernel: FP4 +-1 dot products on "
+                                   "v_mfma_scale_f32_32x32x64_f8f6f4, one-wave workgroups, 256-query tiles)",
+        "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
+        "x_popcount_valu_roofline_measured_issue_rate": fwd_laneops / PEAK_TLANEOPS,
+        "x_popcount_valu_roofline_nominal_64_lanes_per_clk": fwd_laneops / NOMINAL_TLANEOPS,
         "traffic": None,
         "launches": fwd["launches"], "avg_launch_ms": fwd["scan_ms"] / max(1, fwd["launches"]),
-        "algorithmic": "16 int32 VALU lane-ops (8 v_xor_b32 + 8 v_bcnt_u32_b32) per 256-bit comparison x "
+        "algorithmic": "512 FLOP (256 FP4 multiply-adds, exact in the f32 accumulator) per 256-bit comparison x "
                        "comparisons really evaluated per launch (N1*N2 per pair for the forward scan); "
-                       "peak = 1024 SIMDs x 64 lanes x 2.4 GHz / (8 x 2.32 + 8 x 4.61 measured issue cycles) "
-                       "x 16 = 45.4 T lane-ops/s; nominal BASELINE.md peak (64 lanes/clk/CU) = 39.32 T",
+                       "peak = 1024 SIMDs x 4096 FLOP/clk (one 32x32x64 FP4 MFMA per 32 cycles) x 2.4 GHz = 10.07 PFLOP/s "
+                       "= 19.66 T comparisons/s; the popcount (v_xor + v_bcnt) roofline the path was first built to is "
+                       "2.84 T comparisons/s at measured issue rates, 2.46 T nominal",
         "kernel_gcomps": fwd["comparisons"] / (fwd["scan_ms"] * 1e-3) / 1e9,
         "backward_pruned": {"kernel": "scan_kernel<1,8>", "launches": bwd["launches"],
                             "avg_launch_ms": bwd["scan_ms"] / max(1, bwd["launches"]),
@@ -288,7 +297,7 @@ def main():
     out = {
         "metric": "hamming_comparisons_per_sec", "value": evaluated_all / dt / 1e9, "unit": "Gcomp/s",
         "n_gpus": world, "rehearsal_on_one_gpu": bool(a.rehearse), "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp4",
         "data": "synthetic",
         "config": {"workload": "sfm_allpairs_crosscheck", "images": a.images, "desc_per_image": a.desc,
                    "pairs_per_rank_per_step": P, "threshold": a.threshold, "dist_2_best": a.ratio,
@@ -538,8 +547,8 @@ def main():
         nn2_exact = bool(np.array_equal(cbi, bi[:n_slice]) and np.array_equal(cbd, bd[:n_slice])
                          and np.array_equal(csd, sd[:n_slice]))
         extra["nn2_1Mx1M"] = {"seconds": t, "gcomps": n * n / t / 1e9, "kernel_ms": st["scan_ms"],
-                              "roofline_frac": n * float(n) * 16 / (st["scan_ms"] * 1e-3) / 1e12 / PEAK_TLANEOPS,
-                              "frac_of_nominal_64_lanes_per_clk_peak": n * float(n) * 16 / (st["scan_ms"] * 1e-3) / 1e12 / NOMINAL_TLANEOPS,
+                              "roofline_frac": n * float(n) * FLOP_PER_COMP / (st["scan_ms"] * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS,
+                              "x_popcount_valu_roofline_measured_issue_rate": n * float(n) * 16 / (st["scan_ms"] * 1e-3) / 1e12 / PEAK_TLANEOPS,
                               "accepted_thr70_ratio1.2": int(((bd < 70) & (1.2 * bd <= sd)).sum()),
                               "cpu_port_1_thread_gcomps": n_slice * float(n) / t_cpu / 1e9,
                               "cpu_sample": f"{n_slice} queries x 1M train, {t_cpu:.1f} s on 1 core (extrapolates to "

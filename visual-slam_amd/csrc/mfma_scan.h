@@ -184,26 +184,30 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
   }
 }
 
-// Same grid as scan_kernel_adaptive<*, 1, *> (one-wave workgroups): tiles of 32 * NBMAX queries
-// and remainder tiles of half and a quarter of that.
-template <int FMT, int NBMAX>
-__global__ __launch_bounds__(64) void mfma_scan_kernel(const u32x4* __restrict__ qbase,
-                                                       const u32x4* __restrict__ tbase,
-                                                       const Job* __restrict__ jobs, u32 n_jobs, u32 splits,
-                                                       u32 split_stride, uint2* __restrict__ scratch,
-                                                       const u32* __restrict__ qlist, u32 tiles_per_job,
-                                                       u32 d_lim) {
-  const u32 lane = threadIdx.x;
+// WAVES == 1: same grid as scan_kernel_adaptive<*, 1, *> (one-wave workgroups): tiles of
+// 32 * NBMAX queries and remainder tiles of half and a quarter of that, grouped or job-minor
+// block order.  WAVES == 4: same grid as scan_kernel (4-wave workgroups, job-minor), used with
+// NBMAX == 2 for the pruned backward pass, most of whose workgroups find nothing to do.
+template <int FMT, int NBMAX, int WAVES = 1>
+__global__ __launch_bounds__(64 * WAVES) void mfma_scan_kernel(const u32x4* __restrict__ qbase,
+                                                               const u32x4* __restrict__ tbase,
+                                                               const Job* __restrict__ jobs, u32 n_jobs, u32 splits,
+                                                               u32 split_stride, uint2* __restrict__ scratch,
+                                                               const u32* __restrict__ qlist, u32 tiles_per_job,
+                                                               u32 d_lim) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
   u32 job_id, t;
-  if (tiles_per_job) {
+  if (WAVES == 1 && tiles_per_job) {
     const u32 per_group = 8 * tiles_per_job;
     const u32 group = blockIdx.x / per_group, r = blockIdx.x - group * per_group;
     t = r >> 3;
     job_id = group * 8 + (r & 7);
     if (job_id >= n_jobs) return;
   } else {
-    t = blockIdx.x / n_jobs;
-    job_id = blockIdx.x - t * n_jobs;
+    const u32 wg_of_job = blockIdx.x / n_jobs;
+    job_id = blockIdx.x - wg_of_job * n_jobs;
+    t = wg_of_job * WAVES + wave;
   }
   const Job job = jobs[job_id];
   constexpr u32 RMAX = NBMAX / 2;  // tiles are counted in units of 64 queries, as adaptive_tiles does

@@ -382,6 +382,10 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
     }
 #undef VSM_LAUNCH_A
 #undef VSM_LAUNCH_M
+  } else if (sh.mfma && sh.R == 1) {
+    // 64-query tiles in 4-wave workgroups (the pruned backward pass)
+    hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
+                       sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim);
   } else
   // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
   switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
@@ -453,6 +457,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
   shb.R = (vbr == 1 || vbr == 2 || vbr == 4 || vbr == 8) ? vbr : 1;
   shb.wgs_per_job = std::max(1u, ((max_n + 64 * shb.R - 1) / (64 * shb.R) + 3) / 4);
+  // bits 25 / 26 of the experiment knob: popcount scan everywhere / in the backward pass
+  shb.mfma = shb.R == 1 && sh.fkey && !(c->variant & (0x2000000 | 0x4000000));
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
   u32* d_counts = (u32*)c->counts.p;
