@@ -1,7 +1,7 @@
 // tools/mfma_scan.hip -- the matrix-core scan (csrc/mfma_scan.h) against the popcount scan on the
 // same jobs: bitwise comparison of the scratch results and launch times.
 //   hipcc --offload-arch=gfx950 -O3 -I visual-slam_amd/csrc tools/mfma_scan.hip -o /tmp/mfma_scan
-//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim]
+//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim] [plant a true match every k-th descriptor, 0 = none]
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -17,14 +17,14 @@ __device__ inline u32 mix(u32 x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-// Every fourth descriptor index k holds the same base pattern in all images with a few bits
+// Every plant-th descriptor index k holds the same base pattern in all images with a few bits
 // flipped per image (true matches, distance ~ 16); the others are independent random bits.
-__global__ void fill_db(u32* p, u32 n_img, u32 N) {
+__global__ void fill_db(u32* p, u32 n_img, u32 N, u32 plant) {
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= (size_t)n_img * N * 8) return;
   const u32 w = i & 7, k = (i >> 3) % N, img = (i >> 3) / N;
   const u32 r = mix((u32)i * 2654435761u + 12345u);
-  if (k % 4 == 0) {
+  if (plant && k % plant == 0) {
     const u32 base = mix(k * 8 + w + 777u);
     const u32 noise = r & mix(r + 1) & mix(r + 2) & mix(r + 3) & mix(r + 4);
     p[i] = base ^ noise ^ (img & 0);
@@ -36,9 +36,10 @@ __global__ void fill_db(u32* p, u32 n_img, u32 N) {
 int main(int argc, char** argv) {
   const u32 n_img = 512, N = argc > 1 ? atoi(argv[1]) : 2000, P = argc > 2 ? atoi(argv[2]) : 4096;
   const u32 d_lim = argc > 3 ? atoi(argv[3]) : 256;
+  const u32 plant = argc > 4 ? atoi(argv[4]) : 4;
   u32* db;
   CK(hipMalloc(&db, (size_t)n_img * N * 32));
-  fill_db<<<(u32)(((size_t)n_img * N * 8 + 255) / 256), 256>>>(db, n_img, N);
+  fill_db<<<(u32)(((size_t)n_img * N * 8 + 255) / 256), 256>>>(db, n_img, N, plant);
   const u32 stride = (N + 63) / 64 * 64;
   std::vector<Job> jobs(2 * P);
   for (u32 p = 0; p < P; p++) {

@@ -13,4 +13,6 @@ timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 $ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 # Pass 5: kernel trace of a short run WITH the extras (single stereo pair, landmarks, ORB, 1M x 1M)
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_extras -o t -- python3 bench.py --steps 1 --warmup 1 --cpu-pairs 0 --pairs 4096 > $OUT/trace_extras.json 2> $OUT/trace_extras.err
+# Pass 6: matrix-core counters (a pass of its own: if a counter name is unknown only this pass is lost)
+timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/pmc_mfma -o p -- python3 $ARGS > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err || echo "pmc_mfma pass failed"
 find $OUT -type f | head -50

@@ -31,7 +31,7 @@ if os.path.exists(ex):
 with open(os.path.join(dst, "pmc_counters.txt"), "w") as f:
     f.write("# rocprofv3 --pmc <counters> (one run per group) -- same command; per-dispatch averages\n")
     f.write("# columns: kernel | counter | dispatches | avg value per dispatch\n")
-    for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    for d in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_mfma"):
         p = os.path.join(src, d, "p_results.db")
         if not os.path.exists(p):
             continue
@@ -52,9 +52,10 @@ for d, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 pairs = 16384
 json.dump({"kernel": kname, "pairs_per_launch": pairs,
            "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
-           "bytes_per_pair": (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / pairs,
+           "bytes_per_pair": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / pairs,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh); raw counter "
-                   "values in KiB. FETCH_SIZE is NOT doubled: the x2 gfx950 correction of MI355X_MICROARCH.md is "
-                   "calibrated for 16 B/lane streaming reads; this kernel reads through s_load_dwordx8 and "
-                   "global_load_dwordx4, uncalibrated. WRITE_SIZE equals the algorithmic 8 B per query exactly."},
+                   "values in KiB. bytes_per_pair = (2 x FETCH_SIZE + WRITE_SIZE) / pairs: the x2 gfx950 correction of "
+                   "MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of 16 B/lane global loads) applies, the "
+                   "matrix-core scan reads every descriptor through global_load_dwordx4. WRITE_SIZE is exact "
+                   "(8 B per query)."},
           open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)

@@ -126,6 +126,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
     f32x16 D = zero;
 #pragma unroll
     for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[0][m], D);
+    i32x8 An[4] = {A[0], A[1], A[2], A[3]};
     for (u32 j = t0; j < t1; j += 32) {
 #pragma unroll
       for (int b = 0; b < NB; b++) {
@@ -134,15 +135,18 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
 #pragma unroll
           for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[b + 1][m], Dn);
         } else {
-          // next 32 train rows (past the end: the clamped last row again, result unused)
+#pragma unroll
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(An[m], B[0][m], Dn);
+        }
+        if (b == (NB >= 2 ? NB - 2 : 0)) {
+          // operands of the next 32 train rows (past the end: the clamped last row again, result
+          // unused), expanded one step early so that the VALU work sits behind this step's MFMAs
           w = wn;
           wn = tr[2 * (size_t)min(j + 64 + c, last)];
-          A[0] = expand_bits<FMT>(w.x);
-          A[1] = expand_bits<FMT>(w.y);
-          A[2] = expand_bits<FMT>(w.z);
-          A[3] = expand_bits<FMT>(w.w);
-#pragma unroll
-          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[0][m], Dn);
+          An[0] = expand_bits<FMT>(w.x);
+          An[1] = expand_bits<FMT>(w.y);
+          An[2] = expand_bits<FMT>(w.z);
+          An[3] = expand_bits<FMT>(w.w);
         }
         asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the test below (and their result in VGPRs)
 #define DI(k) __float_as_int(D[k])
@@ -150,6 +154,12 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
         const int m3 = min3i(DI(9), DI(10), DI(11)), m4 = min3i(DI(12), DI(13), DI(14));
         const int lo = min(min3i(m0, m1, m2), min3i(m3, m4, DI(15)));
 #undef DI
+        // issue order of a step: two MFMAs, then the minimum tree spread behind the other two
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(lo <= lim[b]) != 0, 0)) {
           // slow path: some lane has a candidate.  Row of element i: (i & 3) + 8 (i >> 2) + 4 h.
           const float cj = MFMA_KEY_BASE + (float)(j - t0 + 4 * h);
@@ -168,6 +178,8 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
         }
         D = Dn;
       }
+#pragma unroll
+      for (int m = 0; m < 4; m++) A[m] = An[m];
     }
   }
 
