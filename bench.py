@@ -281,7 +281,7 @@ def main():
                        "= 19.66 T comparisons/s; the popcount (v_xor + v_bcnt) roofline the path was first built to is "
                        "2.84 T comparisons/s at measured issue rates, 2.46 T nominal",
         "kernel_gcomps": fwd["comparisons"] / (fwd["scan_ms"] * 1e-3) / 1e9,
-        "backward_pruned": {"kernel": "scan_kernel<1,8>", "launches": bwd["launches"],
+        "backward_pruned": {"kernel": "mfma_scan_kernel<4,2,4>", "launches": bwd["launches"],
                             "avg_launch_ms": bwd["scan_ms"] / max(1, bwd["launches"]),
                             "kernel_gcomps": (bwd["comparisons"] / (bwd["scan_ms"] * 1e-3) / 1e9) if bwd["scan_ms"] else None},
         "evaluated_over_reference_equivalent": scan_comps / comps_rank,
@@ -307,6 +307,41 @@ def main():
         "roofline": roofline,
         "setup": {"db_generate_s": t_gen, "db_broadcast_or_upload_s": t_bc, "gather_last_step_ms": gather_ms},
     }
+
+    if world == 1 and not (a.variant & 0x2000000):
+        # The same batch on the popcount (v_xor + v_bcnt) form of the scan, the formulation
+        # BASELINE.json's north_star describes: knob bit 25.  Reported against the integer-VALU
+        # roofline it is bound by; lists compared with the matrix-core run of the same pairs.
+        s_last = n_steps - 1
+        ref_total = run(s_last)
+        ref_offs = d_offsets.clone()
+        ref_out = d_out[:ref_total].clone()
+        m.set_variant(a.variant | 0x2000000)
+        run(s_last)
+        m.set_profiling(True)
+        pk = {"scan_ms": 0.0, "launches": 0, "comparisons": 0}
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            got_total = run(s_last)
+            st = m.last_scan_stats(0)
+            for key in st:
+                pk[key] += st[key]
+        torch.cuda.synchronize()
+        tp = time.perf_counter() - tp
+        m.set_profiling(False)
+        m.set_variant(a.variant)
+        same = bool(got_total == ref_total and torch.equal(ref_offs, d_offsets) and torch.equal(ref_out, d_out[:got_total]))
+        lane = pk["comparisons"] * LANE_OPS_PER_COMP / (pk["scan_ms"] * 1e-3) / 1e12
+        out["popcount_path"] = {
+            "kernel": "scan_kernel_adaptive<8,1,4> (knob bit 25: v_xor_b32 + v_bcnt_u32_b32, no MFMA)",
+            "pairs_per_s": P * reps / tp, "ms_per_step": tp / reps * 1e3,
+            "kernel_gcomps": pk["comparisons"] / (pk["scan_ms"] * 1e-3) / 1e9,
+            "roofline": {"bound": "valu", "achieved": lane, "peak": PEAK_TLANEOPS, "unit": "Tlaneop/s",
+                         "frac": lane / PEAK_TLANEOPS, "frac_of_nominal_64_lanes_per_clk_peak": lane / NOMINAL_TLANEOPS},
+            "lists_identical_to_matrix_core_path": same,
+        }
 
     if a.cpu_pairs > 0 and world == 1:
         n_cpu = min(a.cpu_pairs, P)

@@ -8,7 +8,7 @@
 // v_mfma_f32_32x32x64_f8f6f4 on FP4 (e2m1) operands multiplies a 32 x 64 tile by a 64 x 32 tile
 // in 32 cycles per SIMD, so four of them give the 1024 distances of 32 train x 32 query
 // descriptors in 128 cycles; the popcount path (v_xor + v_bcnt, vsmatch_kernels.h) needs
-// 16 x 55 = 887 cycles for the same 1024 comparisons.  Every product is +1 or -1 and every sum
+// 16 x 55.4 = 887 cycles for the same 1024 comparisons.  Every product is +1 or -1 and every sum
 // an integer of magnitude <= 256, all exact in the f32 accumulator: the distances are the
 // reference's, bit for bit.
 //
@@ -18,17 +18,28 @@
 // i.e. register s takes bits 3-s, 7-s, ... 31-s of the 32-bit word w.  That is a permutation of
 // the 32 k-positions, and a dot product does not care as long as both operands use the same
 // one.  Queries are expanded once per tile (from ~w, so that a product is +1 where the bits
-// DIFFER and the accumulator holds D = 2 d - 256), train descriptors once per 32 x (32 NB)
-// block of comparisons.
+// DIFFER), train descriptors once per 32 x (32 NB) block of comparisons.  The block-scaled form
+// of the instruction multiplies every product by 2^-7 and the accumulator starts at the inline
+// constant 4.0, so a result is D' = 4 + (2 d - 256) / 128 = 2 + d / 64: exact, and positive, so
+// that its bit pattern orders like its value.
 //
 // Tracking.  A lane of the 32x32 result holds 16 train rows of ONE query column, so it keeps
 // its own (best, second) per query block and the two lanes of a column are merged at the end.
-// Per block of 1024 distances the common case is eight v_min3_f32 and a compare: only if some
+// Per block of 1024 distances the common case is eight v_min3_i32 and a compare: only if some
 // lane sees a distance at or below its current second best does the wave take the slow path
 // (float keys d * 32768 + j, v_med3_f32 / v_min_f32, as vsmatch_kernels.h FILL 5).  The start
 // value of (best, second) is a key of distance `d_lim`: the matcher passes the smallest
-// distance that can no longer change the accept test (keypoints.h:295-296), the raw 2-NN entry
-// point passes 256 (everything is tracked, exactly).
+// distance that can no longer change the accept test (keypoints.h:295-296; accept_limit in
+// vsmatch.hip), the raw 2-NN entry point passes 256 (everything is tracked, exactly).
+// (Tracking only the groups of three elements whose minimum passes the test was tried: no
+// gain, 17 more VGPRs.)
+//
+// Measured (tools/mfma_scan.hip, tools/mfma_rate.hip, profiles/r01): 13.6 T comparisons/s on the
+// 5000 x 2000 batch against 2.6 T for the popcount scan; the instruction alone, back to back on
+// random +-1 codes at the same two waves per SIMD, sustains 14.5 T (the chip clocks down to
+// ~1.9 GHz under it), at 2.4 GHz it would be 19.66 T.
+// Build with -mllvm -amdgpu-mfma-vgpr-form: the minimum tree reads the results with VALU
+// instructions, from AGPRs every element would first need a v_accvgpr_read.
 #pragma once
 #include "vsmatch_kernels.h"
 

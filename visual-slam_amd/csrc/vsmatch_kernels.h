@@ -9,8 +9,11 @@
 //   fill_kernel      cross-check (354-360) and ordered compaction of the match list.
 //   finalize_nn2     unpacks the scan result for the raw 2-NN entry point.
 //
-// Integer VALU work only (v_xor_b32 + v_bcnt_u32_b32 with its free accumulate);
-// no MFMA by design: this is a popcount workload, not a contraction.
+// This file: the popcount form of the scan, integer VALU work only (v_xor_b32 +
+// v_bcnt_u32_b32 with its free accumulate).  It serves short jobs (one stereo pair, split
+// scans) and train ranges of more than 32768 descriptors per split; large batches run the
+// matrix-core form in mfma_scan.h (same jobs, same scratch layout, same results), which turned
+// out 5x faster: a Hamming distance is also a +-1 dot product.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
