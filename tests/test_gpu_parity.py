@@ -49,7 +49,7 @@ def test_pair_matches_recorded_reference(m, name):
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
                                      0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008, 0x1000008, 0x1020008,
-                                     0x0308, 0x2000008, 0x2000308, 0x10000008, 0x20000008, 0x40000008, 0x12000008, 0x20000208, 0x4000008])
+                                     0x0308, 0x2000008, 0x2000308, 0x10000008, 0x20000008, 0x40000008, 0x12000008, 0x20000208, 0x4000008, 0x8000001, 0x8000000])
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
     tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile

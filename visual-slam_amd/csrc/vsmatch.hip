@@ -311,7 +311,8 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   const u32 per = (max_nt + s.splits - 1) / s.splits;
   s.fkey = per <= FKEY_MAX_SET && !(variant & 0x20000);
   // bit 25 of the experiment knob: the popcount scan everywhere (A/B runs, parity tests)
-  s.mfma = s.adaptive && s.fkey && s.rmax <= 4 && !(variant & 0x2000000);
+  s.mfma = s.fkey && !(variant & 0x2000000) &&
+           (s.adaptive ? s.rmax <= 4 : (s.R == 1 && !(variant & 0x8000000)));  // bit 27: popcount for short jobs
   return s;
 }
 
