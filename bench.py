@@ -308,7 +308,7 @@ def main():
         "setup": {"db_generate_s": t_gen, "db_broadcast_or_upload_s": t_bc, "gather_last_step_ms": gather_ms},
     }
 
-    if world == 1 and not (a.variant & 0x2000000):
+    if world == 1 and not a.no_extra and not (a.variant & 0x2000000):
         # The same batch on the popcount (v_xor + v_bcnt) form of the scan, the formulation
         # BASELINE.json's north_star describes: knob bit 25.  Reported against the integer-VALU
         # roofline it is bound by; lists compared with the matrix-core run of the same pairs.
