@@ -31,8 +31,10 @@
 // value of (best, second) is a key of distance `d_lim`: the matcher passes the smallest
 // distance that can no longer change the accept test (keypoints.h:295-296; accept_limit in
 // vsmatch.hip), the raw 2-NN entry point passes 256 (everything is tracked, exactly).
-// (Tracking only the groups of three elements whose minimum passes the test was tried: no
-// gain, 17 more VGPRs.)
+// (Tried, no gain: tracking only the groups of three elements whose minimum passes the test
+// (17 more VGPRs); train codes 0.0 / 1.0 instead of +-1.0 with pop(q) folded into the lane's
+// limit -- the bare instruction runs 10 % faster on half-zero operands (tools/mfma_rate.hip,
+// power), this kernel does not: 14.0 T comparisons/s either way on 32768-pair launches.)
 //
 // Measured (tools/mfma_scan.hip, tools/mfma_rate.hip, profiles/r01): 13.6 T comparisons/s on the
 // 5000 x 2000 batch against 2.6 T for the popcount scan; the instruction alone, back to back on
