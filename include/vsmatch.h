@@ -229,6 +229,14 @@ int vsm_last_scan_stats_kind(vsm_ctx* ctx, int kind, double* ms, uint64_t* launc
 int vsm_set_profiling(vsm_ctx* ctx, int enabled);
 /* Kernel variant selector for experiments: 0 = default. See DESIGN.md. */
 int vsm_set_variant(vsm_ctx* ctx, int variant);
+/*
+ * Host-only helper (no GPU, no context; for tests): the distance L in [1, 256] at which the
+ * matrix-core scan starts its best / second best for the accept test of keypoints.h:295-296
+ * with these parameters.  Replacing every best or second best distance >= L by L leaves
+ * `int(best) < threshold && dist_2_best * best <= second` unchanged for all 0 <= best <= second
+ * <= 256; tests/test_abi.py checks that exhaustively.
+ */
+int vsm_accept_limit(int threshold, double dist_2_best);
 
 #ifdef __cplusplus
 }

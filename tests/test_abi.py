@@ -46,6 +46,32 @@ def test_null_context_is_rejected():
     assert b"null context" in L.vsm_last_error()
 
 
+def test_accept_limit_is_invisible_to_the_accept_test():
+    """The matrix-core scan starts best / second best at distance L = vsm_accept_limit(threshold,
+    ratio) (host-only helper).  Exhaustively over 0 <= best <= second <= 256: the accept test of
+    keypoints.h:295-296, `int(best) < threshold && dist_2_best * best <= second` (and best == 256
+    never accepted), gives the same answer on (min(best, L), min(second, L))."""
+    import math
+    import numpy as np
+    L = vsm.matcher.lib()
+    b = np.arange(257)[:, None].astype(np.float64)
+    s = np.arange(257)[None, :].astype(np.float64)
+    tri = b <= s
+    cases = [(thr, r) for thr in (-5, 0, 1, 2, 30, 69, 70, 71, 100, 128, 200, 255, 256, 257, 300, 100000)
+             for r in (0.0, -1.0, 0.5, 0.999, 1.0, 1.01, 1.2, 1.5, 2.0, 3.0, 3.7, 10.0, 300.0, math.inf, -math.inf, math.nan)]
+    for thr, r in cases:
+        lim = L.vsm_accept_limit(thr, r)
+        assert 1 <= lim <= 256, (thr, r, lim)
+
+        def accept(bb, ss):
+            with np.errstate(invalid="ignore"):
+                return (bb < 256) & (bb < thr) & (r * bb <= ss)
+        want = accept(b, s)
+        got = accept(np.minimum(b, lim), np.minimum(s, lim))
+        assert np.array_equal(want[tri.nonzero()], got[tri.nonzero()]), (thr, r, lim)
+    assert L.vsm_accept_limit(70, 1.2) == 83
+
+
 def test_product_never_touches_the_oracle():
     """The package must not import/load anything under oracle/ (the judge checks this)."""
     pkg = os.path.join(ROOT, "visual-slam_amd")

@@ -610,6 +610,12 @@ int vsm_set_profiling(vsm_ctx* c, int enabled) {
   return VSM_OK;
 }
 
+int vsm_accept_limit(int threshold, double dist_2_best) {
+  AcceptParams prm;
+  make_accept(threshold, dist_2_best, &prm);
+  return (int)accept_limit(prm);
+}
+
 int vsm_set_variant(vsm_ctx* c, int variant) {
   VSM_TRY(check_ctx(c));
   std::lock_guard<std::recursive_mutex> lk(c->mu);
