@@ -32,7 +32,7 @@
 // distance that can no longer change the accept test (keypoints.h:295-296; accept_limit in
 // vsmatch.hip), the raw 2-NN entry point passes 256 (everything is tracked, exactly).
 // (Tried, no gain: tracking only the groups of three elements whose minimum passes the test
-// (17 more VGPRs); train codes 0.0 / 1.0 instead of +-1.0 with pop(q) folded into the lane's
+// (17 more VGPRs); a branch per element in the slow path (exact mode 4.9 -> 3.9 T at NB = 8); train codes 0.0 / 1.0 instead of +-1.0 with pop(q) folded into the lane's
 // limit -- the bare instruction runs 10 % faster on half-zero operands (tools/mfma_rate.hip,
 // power), this kernel does not: 14.0 T comparisons/s either way on 32768-pair launches.)
 //

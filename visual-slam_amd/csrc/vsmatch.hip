@@ -449,10 +449,10 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & 0x10000);
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
   // Backward jobs of the pruned pass scan ragged nominated lists whose lengths only the device
-  // knows: one query per lane, fixed 64-query tiles.  (Adaptive tiles were measured here and
-  // lose: a sparse batch has one live wave per job, and the 114-VGPR adaptive kernel holds
-  // half as many of them per SIMD as the 33-VGPR R = 1 kernel -- 0.45 -> 1.18 ms per launch;
-  // a dense batch gets too few, too long waves -- 4.4 -> 5.4 ms.)
+  // knows: fixed 64-query tiles (matrix-core scan: 32 * 2 queries per wave, 4-wave workgroups).
+  // Adaptive tiles were measured here twice and do not pay: with the popcount scan a sparse
+  // batch went 0.45 -> 1.18 ms per launch and a dense one 4.4 -> 5.4 ms; with the matrix-core
+  // scan (256-query tiles) sparse 0.137 -> 0.153 ms, dense 1.59 -> 1.62 ms.
   ScanShape shb = sh;
   shb.adaptive = false;
   const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
