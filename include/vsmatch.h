@@ -230,6 +230,15 @@ int vsm_set_profiling(vsm_ctx* ctx, int enabled);
 /* Kernel variant selector for experiments: 0 = default. See DESIGN.md. */
 int vsm_set_variant(vsm_ctx* ctx, int variant);
 /*
+ * Which tracking form the matrix-core forward scan of the NEXT batched call on this context will
+ * use -- 0 = float keys (fastest when almost no 32 x 32 block holds a distance below the accept
+ * limit: synthetic iid descriptors), 1 = distances with index recovery (real ORB descriptors,
+ * whose unrelated pairs are often closer than the limit) -- and the share of 32 x 32 steps of the
+ * last batched call that left the common path (-1 before the first call).  The library chooses
+ * by itself after every batched call; results are identical either way.
+ */
+int vsm_scan_tracking(vsm_ctx* ctx, int* mode, double* slow_share);
+/*
  * Host-only helper (no GPU, no context; for tests): the distance L in [1, 256] at which the
  * matrix-core scan starts its best / second best for the accept test of keypoints.h:295-296
  * with these parameters.  Replacing every best or second best distance >= L by L leaves

@@ -77,8 +77,8 @@ int main(int argc, char** argv) {
   printf("N=%u pairs=%u d_lim=%u comps/launch=%.3e\n", N, P, d_lim, comps);
   printf("%-28s %8.3f ms %9.1f Gcomp/s\n", "popcount adaptive<8,1,4>", t_ref, comps / (t_ref * 1e-3) / 1e9);
 
-  struct V { const char* name; int fmt, nb; };
-  const V vs[] = {{"mfma fp4 NB8", 4, 8}, {"mfma fp4 NB4", 4, 4}, {"mfma fp8 NB8", 0, 8}, {"mfma fp8 NB4", 0, 4}};
+  struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking
+  const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2}};
   for (const V& v : vs) {
     float tm = 1e30f;
     const u32 tiles = adaptive_tiles(N, v.nb / 2), groups = (n_jobs + 7) / 8;
@@ -87,10 +87,11 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0));
       const dim3 g(groups * 8 * tiles), blk(64);
 #define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
-      if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS);
-      else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS);
-      else if (v.nb == 8) mfma_scan_kernel<0, 8><<<g, blk>>>(ARGS);
-      else mfma_scan_kernel<0, 4><<<g, blk>>>(ARGS);
+      if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr);
+      else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr);
+      else if (v.nb == 8) mfma_scan_kernel<4, 8, 1, 1><<<g, blk>>>(ARGS, nullptr);
+      else if (v.nb == 4) mfma_scan_kernel<4, 4, 1, 1><<<g, blk>>>(ARGS, nullptr);
+      else mfma_scan_kernel<4, 2, 1, 1><<<g, blk>>>(ARGS, nullptr);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());
@@ -113,7 +114,8 @@ int main(int argc, char** argv) {
       if ((e.x >> IDX_BITS) >= d_lim) e.x = sentinel;
       if ((e.y >> IDX_BITS) >= d_lim) e.y = sentinel;
       if ((e.x >> IDX_BITS) < d_lim) cand++;
-      if (e.x != h[i].x || e.y != h[i].y) { if (!bad) first_bad = i; bad++; }
+      // the second best is compared by distance (its index is never read: keypoints.h:296)
+      if (e.x != h[i].x || (e.y >> IDX_BITS) != (h[i].y >> IDX_BITS)) { if (!bad) first_bad = i; bad++; }
     }
     printf("%-28s %8.3f ms %9.1f Gcomp/s  x%.2f  queries with a candidate %zu  %s", v.name, tm, comps / (tm * 1e-3) / 1e9,
            t_ref / tm, cand, bad ? "MISMATCH" : "bit-exact");

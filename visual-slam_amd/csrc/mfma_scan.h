@@ -44,6 +44,7 @@
 // instructions, from AGPRs every element would first need a v_accvgpr_read.
 #pragma once
 #include "vsmatch_kernels.h"
+#include <type_traits>
 
 namespace vsm {
 
@@ -90,16 +91,27 @@ __device__ __forceinline__ int limit_of(float second) {
   return __float_as_int(2.0f + (ceilf(x) - 1.0f) * (1.0f / 64.0f));
 }
 
+// Statistics for the host's choice between the two tracking forms (vsmatch.hip): steps (32 train
+// rows x 32 queries) a wave went through and how many of them left the common path.
+__device__ __forceinline__ void count_steps(unsigned long long* stats, u32 lane, u32 steps, u32 slow) {
+  if (stats && lane == 0) {
+    atomicAdd(stats, (unsigned long long)steps);
+    if (slow) atomicAdd(stats + 1, (unsigned long long)slow);
+  }
+}
+
 // One tile = 32 * NB queries of a job (lane l: column l & 31 of each block of 32, half l >> 5 of
 // the k range) against the split's share of the train range, 32 rows at a time.
 template <int NB, int FMT>
 __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
                                                const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
                                                u32 split_stride, uint2* __restrict__ scratch,
-                                               const u32* __restrict__ qlist, u32 d_lim) {
+                                               const u32* __restrict__ qlist, u32 d_lim,
+                                               unsigned long long* __restrict__ stats) {
   const u32 per = (job.nt + splits - 1) / splits;
   const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
   const u32 c = lane & 31, h = lane >> 5;
+  u32 slow_steps = 0;
 
   i32x8 B[NB][4];
   u32 col[NB];
@@ -174,6 +186,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(lo <= lim[b]) != 0, 0)) {
+          slow_steps++;
           // slow path: some lane has a candidate.  Row of element i: (i & 3) + 8 (i >> 2) + 4 h.
           const float cj = MFMA_KEY_BASE + (float)(j - t0 + 4 * h);
           float bb = best[b], ss = second[b];
@@ -196,6 +209,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
     }
   }
 
+  count_steps(stats, lane, (t1 - t0 + 31) / 32 * NB, slow_steps);
   uint2* out = scratch + (size_t)split * split_stride + job.out_off;
 #pragma unroll
   for (int b = 0; b < NB; b++) {
@@ -209,17 +223,226 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
   }
 }
 
+// ---- Distance-only tracking (TRACK 1) ------------------------------------------------------
+// The tile above tracks float keys d * 32768 + j, ~90 instructions whenever some lane of the wave
+// has a distance at or below its second best.  On iid random bits that is rare; on REAL ORB
+// descriptors it is not: unrelated descriptors are 126 +- 19 bits apart (tests/golden/ex3_kd*),
+// 2 % of all pairs are below the accept limit of 83 and 95 % of the 32 x 32 blocks hold one,
+// so the slow path ran in nearly every step: 5.3 T comparisons/s instead of 13.8 T
+// (tools/real_like_probe.py).  This tile tracks the two smallest DISTANCES only: the same
+// eight-instruction minimum and test, then a 12-instruction tournament for the two smallest of the
+// lane's sixteen results and five instructions to merge them into (best, second) and to remember
+// the 32-row step in which the lane's best last improved.  The train INDEX of the best is
+// recovered at the end of the scan: the lane recomputes the distances of the 16 rows it owns in
+// that step with v_xor / v_bcnt and takes the lowest row that has the best distance -- the
+// reference's "strict <, ascending scan" (keypoints.h:273) exactly: the remembered step is the
+// first one that reached the final best distance, and rows are taken in ascending order.  The
+// second best needs no index (keypoints.h:296 reads its distance only).
+template <int NB, int FMT>
+__device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
+                                                 const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
+                                                 u32 split_stride, uint2* __restrict__ scratch,
+                                                 const u32* __restrict__ qlist, u32 d_lim,
+                                                 unsigned long long* __restrict__ stats) {
+  const u32 per = (job.nt + splits - 1) / splits;
+  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
+  const u32 c = lane & 31, h = lane >> 5;
+  u32 slow_steps = 0;
+
+  i32x8 B[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const u32 qi = min(q0 + b * 32 + c, job.nq - 1);
+    const u32 colb = job.qlist_off != NO_QLIST ? qlist[job.qlist_off + qi] : qi;
+    const u32x4 w = qbase[2 * (size_t)(job.q_off + colb) + h];
+    B[b][0] = expand_bits<FMT>(~w.x);
+    B[b][1] = expand_bits<FMT>(~w.y);
+    B[b][2] = expand_bits<FMT>(~w.z);
+    B[b][3] = expand_bits<FMT>(~w.w);
+  }
+  const float dlim = 2.0f + (float)d_lim * (1.0f / 64.0f);  // D' of distance d_lim
+  // `best` carries, in the 10 lowest mantissa bits of its D' (one distance unit is 2^15 or 2^16
+  // units in the last place, a range has at most 1024 steps of 32 rows), the number of the step
+  // in which it was found: v_min then keeps the EARLIEST step of equal distances, which is what
+  // the index recovery needs, at the price of one v_or per slow step and no register.
+  float best[NB], second[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) best[b] = second[b] = dlim;
+
+  if (t1 > t0) {
+    const u32x4* tr = tbase + 2 * (size_t)job.t_off + h;
+    const u32 last = t1 - 1;
+    const float z = MFMA_BIAS;
+    const f32x16 zero = {z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z};
+    u32x4 w = tr[2 * (size_t)min(t0 + c, last)];
+    u32x4 wn = tr[2 * (size_t)min(t0 + 32 + c, last)];
+    i32x8 A[4];
+    A[0] = expand_bits<FMT>(w.x);
+    A[1] = expand_bits<FMT>(w.y);
+    A[2] = expand_bits<FMT>(w.z);
+    A[3] = expand_bits<FMT>(w.w);
+    f32x16 D = zero;
+#pragma unroll
+    for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[0][m], D);
+    i32x8 An[4] = {A[0], A[1], A[2], A[3]};
+    u32 step = 0;
+    for (u32 j = t0; j < t1; j += 32, step++) {
+      // one body per 32 train rows; the masked form only for the last, partial step of a range
+      auto body = [&](auto masked) {
+        const u32 left = t1 - j - 4 * h;      // the lane's rows at offsets < left exist ...
+        const bool any_row = j + 4 * h < t1;  // ... if any does
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          f32x16 Dn = zero;
+          if (b + 1 < NB) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[b + 1][m], Dn);
+          } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(An[m], B[0][m], Dn);
+          }
+          if (b == (NB >= 2 ? NB - 2 : 0)) {
+            w = wn;
+            wn = tr[2 * (size_t)min(j + 64 + c, last)];
+            An[0] = expand_bits<FMT>(w.x);
+            An[1] = expand_bits<FMT>(w.y);
+            An[2] = expand_bits<FMT>(w.z);
+            An[3] = expand_bits<FMT>(w.w);
+          }
+          asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the test below (and their result in VGPRs)
+          // x[i] as integers: D' is a positive float, its bit pattern orders like its value
+          int x[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) {
+            x[i] = __float_as_int(D[i]);
+            if (decltype(masked)::value) {
+              const u32 off = (u32)((i & 3) + 8 * (i >> 2));
+              x[i] = (any_row && off < left) ? x[i] : 0x41000000;  // 8.0: rows past the end are farther than anything
+            }
+          }
+          // smallest element of the lane: five triples and the sixteenth element
+          int m1;
+          {
+            const int l0 = min3i(x[0], x[1], x[2]), l1 = min3i(x[3], x[4], x[5]), l2 = min3i(x[6], x[7], x[8]);
+            const int l3 = min3i(x[9], x[10], x[11]), l4 = min3i(x[12], x[13], x[14]);
+            m1 = min(min3i(l0, l1, l2), min3i(l3, l4, x[15]));
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(m1 < __float_as_int(second[b])) != 0, 0)) {
+            slow_steps++;
+            // Some lane has an element below its second best: the two smallest of the sixteen by
+            // a tournament (the median of a triple is its second smallest, and the second
+            // smallest of all is the second smallest of the triples' minima or one of their
+            // medians), then merged into (best, second).  Everything is recomputed from the
+            // sixteen results here: values kept alive across the branch cost registers in the
+            // common path.
+            auto med3 = [](int p, int q, int r) {
+              return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
+            };
+            int xx[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              xx[i] = x[i];
+            }
+            int lo[5], mid[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+              lo[k] = min3i(xx[3 * k], xx[3 * k + 1], xx[3 * k + 2]);
+              mid[k] = med3(xx[3 * k], xx[3 * k + 1], xx[3 * k + 2]);
+            }
+            const int a1 = min3i(lo[0], lo[1], lo[2]), b1 = min3i(lo[3], lo[4], xx[15]);
+            const int a2 = med3(lo[0], lo[1], lo[2]), b2 = med3(lo[3], lo[4], xx[15]);
+            const int mm1 = min(a1, b1);
+            const int sl = min3i(max(a1, b1), a2, b2);
+            const int m2 = min(min3i(mid[0], mid[1], mid[2]), min3i(mid[3], mid[4], sl));
+            const int ob = __float_as_int(best[b]), os = __float_as_int(second[b]);
+            const int nb = min(ob, mm1 | (int)step);
+            const int ns = min3i(max(ob & ~1023, mm1), os, m2);
+            best[b] = __int_as_float(nb);
+            second[b] = __int_as_float(ns);
+          }
+          D = Dn;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) A[m] = An[m];
+      };
+      if (__builtin_expect(j + 32 > t1, 0)) body(std::true_type{});
+      else body(std::false_type{});
+    }
+  }
+
+  // Epilogue.  Everything it needs besides (best, second) is recomputed from q0,
+  // laundered through an empty asm so that the compiler cannot hoist it above the scan and keep
+  // it in registers there (it did: 16 address registers and col[] spilled around the loop).
+  u32 q0e = q0;
+  asm volatile("" : "+s"(q0e));
+  count_steps(stats, lane, (t1 - t0 + 31) / 32 * NB, slow_steps);
+  uint2* out = scratch + (size_t)split * split_stride + job.out_off;
+  const u32 sentinel = d_lim >= 256u ? KEY_INIT : ((d_lim << IDX_BITS) | t0);
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    // the two halves of the wave hold the same query columns over disjoint train rows
+    const u32 my_step = __float_as_uint(best[b]) & 1023u;
+    const float mb = __uint_as_float(__float_as_uint(best[b]) & ~1023u);  // D' of the lane's best alone
+    const float ob = __shfl_xor(mb, 32), os = __shfl_xor(second[b], 32);
+    const float fb = fminf(mb, ob);
+    const float fs = fminf(fminf(second[b], os), fmaxf(mb, ob));
+    const u32 db = (u32)((fb - 2.0f) * 64.0f), ds = (u32)((fs - 2.0f) * 64.0f);
+    const u32 qi = q0e + b * 32 + c;
+    const u32 qc = min(qi, job.nq - 1);
+    const u32 colb = job.qlist_off != NO_QLIST ? qlist[job.qlist_off + qc] : qc;
+    u32 idx = 0xffffffffu;
+    const bool mine = fb < dlim && mb == fb;  // this half reached the final best distance
+    if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+      // index recovery: the lowest of the lane's 16 rows of that step at distance db
+      const u32x4* qp = qbase + 2 * (size_t)(job.q_off + colb);
+      const u32x4 qa = qp[0], qb = qp[1];
+      const u32 base = t0 + 32 * (mine ? my_step : 0u) + 4 * h;
+      const u32x4* tp = tbase + 2 * (size_t)job.t_off;
+      // four consecutive rows (128 contiguous bytes) per iteration, all eight loads in flight
+      // together; descending, so that the lowest row is assigned last and wins
+#pragma unroll 1
+      for (int g = 3; g >= 0; g--) {
+        const u32 r0 = base + 8 * (u32)g;
+        u32x4 ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 rc = min(r0 + k, t1 - 1);
+          ta[k] = tp[2 * (size_t)rc];
+          tb[k] = tp[2 * (size_t)rc + 1];
+        }
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+          const u32 d = __popc(qa.x ^ ta[k].x) + __popc(qa.y ^ ta[k].y) + __popc(qa.z ^ ta[k].z) + __popc(qa.w ^ ta[k].w) +
+                        __popc(qb.x ^ tb[k].x) + __popc(qb.y ^ tb[k].y) + __popc(qb.z ^ tb[k].z) + __popc(qb.w ^ tb[k].w);
+          if (mine && r0 + k < t1 && d == db) idx = r0 + k;
+        }
+      }
+    }
+    const u32 fidx = min(idx, (u32)__shfl_xor((int)idx, 32));
+    if (h == 0 && qi < job.nq) {
+      const u32 kb = fb < dlim ? ((db << IDX_BITS) | fidx) : sentinel;
+      const u32 ks = fs < dlim ? (ds << IDX_BITS) : sentinel;
+      out[colb] = make_uint2(kb, ks);
+    }
+  }
+}
+
 // WAVES == 1: same grid as scan_kernel_adaptive<*, 1, *> (one-wave workgroups): tiles of
 // 32 * NBMAX queries and remainder tiles of half and a quarter of that, grouped or job-minor
 // block order.  WAVES == 4: same grid as scan_kernel (4-wave workgroups, job-minor), used with
 // NBMAX == 2 for the pruned backward pass, most of whose workgroups find nothing to do.
-template <int FMT, int NBMAX, int WAVES = 1>
-__global__ __launch_bounds__(64 * WAVES) void mfma_scan_kernel(const u32x4* __restrict__ qbase,
+template <int FMT, int NBMAX, int WAVES = 1, int TRACK = 0>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_kernel(const u32x4* __restrict__ qbase,
                                                                const u32x4* __restrict__ tbase,
                                                                const Job* __restrict__ jobs, u32 n_jobs, u32 splits,
                                                                u32 split_stride, uint2* __restrict__ scratch,
                                                                const u32* __restrict__ qlist, u32 tiles_per_job,
-                                                               u32 d_lim) {
+                                                               u32 d_lim, unsigned long long* __restrict__ stats) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   u32 job_id, t;
@@ -238,20 +461,24 @@ __global__ __launch_bounds__(64 * WAVES) void mfma_scan_kernel(const u32x4* __re
   constexpr u32 RMAX = NBMAX / 2;  // tiles are counted in units of 64 queries, as adaptive_tiles does
   const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
   if (t < full) {
-    mfma_scan_tile<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim);
+    if (TRACK) mfma_scan_tile_d<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+    else mfma_scan_tile<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
     return;
   }
   u32 k = t - full, q0 = full * 64 * RMAX;
   if (RMAX > 2 && (rem & 2)) {
     if (k == 0) {
-      mfma_scan_tile<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim);
+      if (TRACK) mfma_scan_tile_d<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+      else mfma_scan_tile<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
       return;
     }
     k--;
     q0 += 128;
   }
-  if ((rem & 1) && k == 0)
-    mfma_scan_tile<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim);
+  if ((rem & 1) && k == 0) {
+    if (TRACK) mfma_scan_tile_d<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+    else mfma_scan_tile<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+  }
 }
 
 }  // namespace vsm

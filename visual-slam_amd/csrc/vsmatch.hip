@@ -140,6 +140,11 @@ struct vsm_ctx {
   u64 scan_launches[2] = {0, 0}, scan_comps[2] = {0, 0};
   std::vector<int> ev_kind;
   int variant = 0;
+  // Tracking form of the matrix-core forward scan: 1 = distances (robust: real descriptors,
+  // many near neighbours), 0 = float keys (fastest when almost no step leaves the common path).
+  // Chosen after every batched call from the share of steps that did (mfma_scan.h count_steps).
+  int scan_track = 1;
+  double last_slow_share = -1.0;
 };
 
 namespace {
@@ -318,7 +323,7 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
 
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
-                const u32* d_qlist = nullptr, u32 d_lim = 256) {
+                const u32* d_qlist = nullptr, u32 d_lim = 256, unsigned long long* d_stats = nullptr) {
   const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
   const u64 blocks = n_jobs * sh.wgs_per_job;
@@ -359,8 +364,19 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
                      sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
 #define VSM_LAUNCH_M(NN)                                                                               \
   hipLaunchKernelGGL((mfma_scan_kernel<4, NN>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim)
-    if (sh.mfma && w1) {  // shipped: FP4 matrix-core scan, 32 * NN queries per wave
+                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats)
+#define VSM_LAUNCH_MD(NN)                                                                              \
+  hipLaunchKernelGGL((mfma_scan_kernel<4, NN, 1, 1>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
+                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats)
+    // Tracking form: the context's current choice (see scan_track); knob nibble 20-23 = 14 / 13
+    // forces distances / keys.  Backward scans (query lists) keep the key form.
+    const int vtr = (c->variant >> 20) & 0xf;
+    const bool track_d = vtr == 14 || (vtr != 13 && c->scan_track == 1 && !d_qlist);
+    if (sh.mfma && w1 && track_d) {
+      if (sh.rmax == 4) VSM_LAUNCH_MD(8);
+      else if (sh.rmax == 2) VSM_LAUNCH_MD(4);
+      else VSM_LAUNCH_MD(2);
+    } else if (sh.mfma && w1) {  // shipped: FP4 matrix-core scan, 32 * NN queries per wave
       if (sh.rmax == 4) VSM_LAUNCH_M(8);
       else if (sh.rmax == 2) VSM_LAUNCH_M(4);
       else VSM_LAUNCH_M(2);
@@ -383,10 +399,11 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
     }
 #undef VSM_LAUNCH_A
 #undef VSM_LAUNCH_M
+#undef VSM_LAUNCH_MD
   } else if (sh.mfma && sh.R == 1) {
     // 64-query tiles in 4-wave workgroups (the pruned backward pass)
     hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
-                       sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim);
+                       sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr);
   } else
   // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
   switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
@@ -422,7 +439,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   u64* d_running = (u64*)c->misc.p;
   u64* d_comps = d_running + 1;
   u32* d_bad = (u32*)(d_running + 3);
-  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 32, c->stream));
+  unsigned long long* d_stats = (unsigned long long*)(d_running + 4);  // [steps][steps off the common path]
+  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 48, c->stream));
   if (n_pairs == 0) {
     HIP_TRY(hipMemsetAsync(d_out_offsets, 0, sizeof(u64), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -472,14 +490,14 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        prune ? 1u : 2u);
     HIP_TRY(hipGetLastError());
     if (prune) {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
                          stride, (u32*)c->qlist.p, d_comps + 1);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
     } else {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats));
     }
     if (sh.splits > 1) {
       const u32 n_entries = n * 2 * stride;
@@ -501,9 +519,18 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     u64 total, comps_fwd, comps_bwd;
     u32 bad;
     u32 pad;
+    u64 steps, slow;
   } h;
-  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 48, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // Next call's tracking form.  A step off the common path costs ~450 cycles with keys and ~100
+  // with distances, whose common path is ~15 % slower: break-even near 8 % of the steps.
+  if (h.steps >= 4096) {
+    const double share = (double)h.slow / (double)h.steps;
+    c->last_slow_share = share;
+    if (share > 0.10) c->scan_track = 1;
+    else if (share < 0.05) c->scan_track = 0;
+  }
   if (c->profiling) VSM_TRY(stats_collect(c));
   c->scan_comps[0] = h.comps_fwd;
   c->scan_comps[1] = h.comps_bwd;
@@ -607,6 +634,13 @@ int vsm_set_profiling(vsm_ctx* c, int enabled) {
   VSM_TRY(check_ctx(c));
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   c->profiling = enabled != 0;
+  return VSM_OK;
+}
+
+int vsm_scan_tracking(vsm_ctx* c, int* mode, double* slow_share) {
+  if (!c) return fail(VSM_ERR_INVALID, "null context");
+  if (mode) *mode = c->scan_track;
+  if (slow_share) *slow_share = c->last_slow_share;
   return VSM_OK;
 }
 
