@@ -49,13 +49,15 @@ def test_pair_matches_recorded_reference(m, name):
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
                                      0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008, 0x1000008, 0x1020008,
-                                     0x0308, 0x2000008, 0x2000308, 0x10000008, 0x20000008, 0x40000008, 0x12000008, 0x20000208, 0x4000008, 0x8000001, 0x8000000])
+                                     0x0308, 0x2000008, 0x2000308, 0x10000008, 0x20000008, 0x40000008, 0x12000008, 0x20000208, 0x4000008, 0x8000001, 0x8000000,
+                                     0xE00008, 0xD00008, 0xC00008, 0x10E00008, 0x20E00008, 0xE00308, 0xE00001, 0xD00001])
 def test_pair_all_kernel_shapes(m, variant):
     """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
     tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
     decomposition unless bit 18 is set -- on the matrix cores (mfma_scan.h) unless bit 25 asks
     for the popcount scan; bits 28-30 force the tile size; bits 19 / 24 select earlier popcount
-    forms: 512-query tiles without the skip test, one-wave / 4-wave workgroups) gives
+    forms: 512-query tiles without the skip test, one-wave / 4-wave workgroups; nibble 20-23 =
+    14 / 13 / 12 forces the distance form / the key form / distances in forward scans only) gives
     the same list."""
     m.set_variant(variant)
     try:
@@ -74,7 +76,7 @@ def test_accept_limit_of_the_matrix_core_scan(m, thr, ratio):
     """The matrix-core scan starts (best, second) at the smallest distance the accept test
     cannot tell from anything larger (accept_limit, vsmatch.hip); whatever threshold and ratio
     that limit is derived from, the list is the oracle's."""
-    for variant in (8, 0x10000008, 0x0308):
+    for variant in (0xD00008, 0x10D00008, 0xD00308, 0xE00008, 0x10E00008, 0xE00308):
         m.set_variant(variant)
         try:
             for (n1, n2, seed) in [(300, 777, 1), (1023, 1025, 2), (64, 33, 3), (5, 2000, 4)]:
@@ -85,8 +87,54 @@ def test_accept_limit_of_the_matrix_core_scan(m, thr, ratio):
             m.set_variant(0)
 
 
+def _real_like_database(n_img, n_desc, seed):
+    """Images drawn from the reference's 1084 real ORB descriptors (ex3 kd0 + kd1), a few bits
+    flipped per copy: unrelated descriptors are 126 +- 19 bits apart, as in real images."""
+    real = np.concatenate(cases.ex3())
+    rng = np.random.default_rng(seed)
+    parts = [real[rng.choice(len(real), size=n_desc, replace=n_desc > len(real))]
+             ^ cases.synth.flip_masks(n_desc, seed, 700 + i, levels=(5,)) for i in range(n_img)]
+    db = np.ascontiguousarray(np.concatenate(parts))
+    return db, (np.arange(n_img + 1) * n_desc).astype(np.uint32)
+
+
+def test_tracking_form_follows_the_data_and_never_changes_the_lists():
+    """The matrix-core forward scan has two tracking forms (mfma_scan.h); the context picks one
+    after every batched call from the share of steps that left the common path.  Real-like
+    descriptors -> distances, iid random ones -> keys; the lists equal the oracle's under either
+    form, forced or chosen, pruned backward pass included."""
+    with vsm.Matcher(0) as mm:
+        assert mm.scan_tracking() == (1, -1.0)
+        db, off = _real_like_database(64, 900, 5)  # 2016 pairs: enough waves for the batched (adaptive) scan
+        pairs = cases.synth.all_pairs(64)
+        mm.db_upload(db, off)
+        want = [binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2) for i, j in pairs.tolist()]
+        assert sum(len(w) for w in want) > 10000
+        for variant in (0, 0, 0xE00000, 0xD00000, 0xC00000, 0x2000000):
+            mm.set_variant(variant)
+            offs, out = mm.match_pairs(pairs, 70, 1.2)
+            for k, w in enumerate(want):
+                assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], w), (hex(variant), k)
+            mode, share = mm.scan_tracking()
+            if variant != 0x2000000:
+                assert mode == 1 and share > 0.5, (hex(variant), mode, share)
+        mm.set_variant(0)
+        db, off = cases.synth.sfm_database(70, 1000, seed=12)
+        pairs = cases.synth.all_pairs(70)
+        mm.db_upload(db, off)
+        o1, l1 = mm.match_pairs(pairs, 70, 1.2)      # still the distance form
+        mode, share = mm.scan_tracking()
+        assert mode == 0 and 0 <= share < 0.05, (mode, share)
+        o2, l2 = mm.match_pairs(pairs, 70, 1.2)      # now keys
+        assert np.array_equal(o1, o2) and np.array_equal(l1, l2)
+        for k in range(0, len(pairs), 37):
+            i, j = pairs[k]
+            assert np.array_equal(l2[int(o2[k]):int(o2[k + 1])],
+                                  binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2))
+
+
 def test_nn2_vs_oracle(m):
-    for variant in (0, 0x20000, 8, 0x2000008, 0x10000008):
+    for variant in (0, 0x20000, 8, 0x2000008, 0x10000008, 0xD00008, 0x10D00008, 0xE00001):
         m.set_variant(variant)
         try:
             for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6),

@@ -323,7 +323,8 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
 
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
-                const u32* d_qlist = nullptr, u32 d_lim = 256, unsigned long long* d_stats = nullptr) {
+                const u32* d_qlist = nullptr, u32 d_lim = 256, unsigned long long* d_stats = nullptr,
+                int track = -1) {  // tracking form: 1 distances, 0 keys, -1 the context's current choice
   const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
   const u64 blocks = n_jobs * sh.wgs_per_job;
@@ -369,9 +370,9 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   hipLaunchKernelGGL((mfma_scan_kernel<4, NN, 1, 1>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
                      sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats)
     // Tracking form: the context's current choice (see scan_track); knob nibble 20-23 = 14 / 13
-    // forces distances / keys.  Backward scans (query lists) keep the key form.
+    // forces distances / keys everywhere, 12 = distances in forward scans, keys elsewhere.
     const int vtr = (c->variant >> 20) & 0xf;
-    const bool track_d = vtr == 14 || (vtr != 13 && c->scan_track == 1 && !d_qlist);
+    const bool track_d = vtr == 14 || vtr == 12 || (vtr != 13 && (track >= 0 ? track == 1 : c->scan_track == 1));
     if (sh.mfma && w1 && track_d) {
       if (sh.rmax == 4) VSM_LAUNCH_MD(8);
       else if (sh.rmax == 2) VSM_LAUNCH_MD(4);
@@ -402,8 +403,15 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #undef VSM_LAUNCH_MD
   } else if (sh.mfma && sh.R == 1) {
     // 64-query tiles in 4-wave workgroups (the pruned backward pass)
-    hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
-                       sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr);
+    const int vtr = (c->variant >> 20) & 0xf;
+    // query lists (pruned backward pass) follow the forward scan's form; one short pair keeps the
+    // keys (the index recovery of the distance form costs it 3 us of 56)
+    if (vtr == 14 || (vtr != 13 && vtr != 12 && (track >= 0 ? track == 1 : (d_qlist && c->scan_track == 1))))
+      hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4, 1>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
+                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr);
+    else
+      hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
+                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr);
   } else
   // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
   switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
@@ -525,7 +533,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   HIP_TRY(hipStreamSynchronize(c->stream));
   // Next call's tracking form.  A step off the common path costs ~450 cycles with keys and ~100
   // with distances, whose common path is ~15 % slower: break-even near 8 % of the steps.
-  if (h.steps >= 4096) {
+  if (h.steps >= 1024) {  // a 1-in-64 sample of the workgroups
     const double share = (double)h.slow / (double)h.steps;
     c->last_slow_share = share;
     if (share > 0.10) c->scan_track = 1;
@@ -816,8 +824,10 @@ int vsm_nn2_device(vsm_ctx* c, const void* d_query, size_t nq, const void* d_tra
   Job j = {0, (u32)nq, 0, (u32)nt, 0, NO_QLIST, 0, 0};
   memcpy(c->pin.p, &j, sizeof j);
   HIP_TRY(hipMemcpyAsync(c->jobs.p, c->pin.p, sizeof j, hipMemcpyHostToDevice, c->stream));
+  // everything is tracked here (start distance 256): the distance form is the faster one
+  // (1M x 1M: 93 ms against 120 ms with keys)
   VSM_TRY(launch_scan(c, d_query, nt ? d_train : d_query, (const Job*)c->jobs.p, 1, sh, split_stride,
-                      (uint2*)c->scratch.p, (u64)nq * nt));
+                      (uint2*)c->scratch.p, (u64)nq * nt, nullptr, 256, nullptr, 1));
   hipLaunchKernelGGL(finalize_nn2_kernel, dim3((u32)((nq + 255) / 256)), dim3(256), 0, c->stream,
                      (const uint2*)c->scratch.p, (u32)nq, sh.splits, split_stride, (int*)d_best_idx,
                      (int*)d_best_dist, (int*)d_second_dist);
