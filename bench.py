@@ -558,6 +558,54 @@ def main():
                                         "backward_scan_ms": dk[1]["scan_ms"],
                                         "backward_gcomps": dk[1]["comparisons"] / max(dk[1]["scan_ms"], 1e-9) / 1e6}
         md.close()
+        # Descriptors with the distance statistics of REAL ORB descriptors: every image is a random
+        # draw from the 1084 descriptors of the reference's ex3 stereo pair (tests/golden) with ~8
+        # bits flipped per copy.  Unrelated descriptors are 126 +- 19 bits apart (iid bits: 128 +- 8),
+        # 2 % of all pairs lie below the accept limit of 83: the regime the distance form of the
+        # matrix-core scan exists for (the context picks it by itself after the first call).
+        gold = os.path.join(ROOT, "tests", "golden")
+        if os.path.exists(os.path.join(gold, "ex3_kd0.npy")):
+            real = np.concatenate([np.load(os.path.join(gold, "ex3_kd0.npy")), np.load(os.path.join(gold, "ex3_kd1.npy"))])
+            rrng = np.random.default_rng(a.seed + 9)
+            n_ri, n_rd = 200, a.desc
+            rdb = np.ascontiguousarray(np.concatenate(
+                [real[rrng.choice(len(real), size=n_rd, replace=n_rd > len(real))]
+                 ^ synth.flip_masks(n_rd, a.seed + 9, 500 + i, levels=(5,)) for i in range(n_ri)]))
+            roff2 = (np.arange(n_ri + 1) * n_rd).astype(np.uint32)
+            rp = synth.all_pairs(n_ri)
+            mr = vsm.Matcher(local)
+            mr.db_upload(rdb, roff2)
+            rpd = torch.from_numpy(rp.view(np.int32).copy()).to(dev)
+            roffs2 = torch.empty(len(rp) + 1, dtype=torch.int64, device=dev)
+            rout2 = torch.empty((len(rp) * n_rd, 2), dtype=torch.int32, device=dev)
+            rl = {}
+            for name, variant in (("chosen", 0), ("key_form_forced", 0xD00000), ("popcount_scan", 0x2000000)):
+                mr.set_variant(variant)
+                mr.set_profiling(True)
+                for _ in range(2):
+                    torch.cuda.synchronize()
+                    t = time.perf_counter()
+                    tot = mr.match_pairs_device(rpd.data_ptr(), len(rp), a.threshold, a.ratio, roffs2.data_ptr(),
+                                                rout2.data_ptr(), len(rp) * n_rd)
+                    t = time.perf_counter() - t
+                k0, k1 = mr.last_scan_stats(0), mr.last_scan_stats(1)
+                mr.set_profiling(False)
+                rl[name] = {"pairs_per_s": len(rp) / t, "total_ms": t * 1e3, "forward_scan_ms": k0["scan_ms"],
+                            "forward_gcomps": k0["comparisons"] / max(k0["scan_ms"], 1e-9) / 1e6,
+                            "backward_scan_ms": k1["scan_ms"], "matches_per_pair": tot / len(rp)}
+                if name == "chosen":
+                    mode, share = mr.scan_tracking()
+                    rl[name]["tracking_form"] = "distances" if mode == 1 else "keys"
+                    rl[name]["share_of_steps_off_the_common_path"] = share
+                    chk = rrng.choice(len(rp), size=24, replace=False)
+                    oh = roffs2.cpu().numpy()
+                    impl = _ob.ref() or _ob.port()
+                    rl["sample_of_24_pairs_equals_cpu_" + impl.kind] = all(
+                        np.array_equal(rout2[int(oh[k]):int(oh[k + 1])].cpu().numpy(),
+                                       impl.match(rdb[roff2[rp[k][0]]:roff2[rp[k][0] + 1]], rdb[roff2[rp[k][1]]:roff2[rp[k][1] + 1]],
+                                                  a.threshold, a.ratio)) for k in chk.tolist())
+            mr.close()
+            extra["real_orb_statistics_200img_19900pairs"] = rl
         # config 4: 1M x 1M one direction (1-NN + ratio test inputs), device resident
         n = 1 << 20
         qa, tb = synth.planted_sets(n, a.seed + 2)
