@@ -290,93 +290,100 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
 #pragma unroll
     for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[0][m], D);
     i32x8 An[4] = {A[0], A[1], A[2], A[3]};
-    u32 step = 0;
-    for (u32 j = t0; j < t1; j += 32, step++) {
-      // one body per 32 train rows; the masked form only for the last, partial step of a range
-      auto body = [&](auto masked) {
-        const u32 left = t1 - j - 4 * h;      // the lane's rows at offsets < left exist ...
-        const bool any_row = j + 4 * h < t1;  // ... if any does
+    // the two smallest of the lane's sixteen results merged into (best, second) of block b
+    auto med3 = [](int p, int q, int r) {
+      return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
+    };
+    auto tournament = [&](const int (&x)[16], int b, u32 step) {
+      int lo[5], mid[5];
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
-          f32x16 Dn = zero;
-          if (b + 1 < NB) {
+      for (int k = 0; k < 5; k++) {
+        lo[k] = min3i(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
+        mid[k] = med3(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
+      }
+      const int a1 = min3i(lo[0], lo[1], lo[2]), b1 = min3i(lo[3], lo[4], x[15]);
+      const int a2 = med3(lo[0], lo[1], lo[2]), b2 = med3(lo[3], lo[4], x[15]);
+      const int mm1 = min(a1, b1);
+      const int sl = min3i(max(a1, b1), a2, b2);
+      const int m2 = min(min3i(mid[0], mid[1], mid[2]), min3i(mid[3], mid[4], sl));
+      const int ob = __float_as_int(best[b]), os = __float_as_int(second[b]);
+      best[b] = __int_as_float(min(ob, mm1 | (int)step));
+      second[b] = __int_as_float(min3i(max(ob & ~1023, mm1), os, m2));
+    };
+    u32 step = 0, j = t0;
+    // Full steps of 32 train rows, software pipelined as in the key form.
+    for (; j + 32 <= t1; j += 32, step++) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[b + 1][m], Dn);
-          } else {
+      for (int b = 0; b < NB; b++) {
+        f32x16 Dn = zero;
+        if (b + 1 < NB) {
 #pragma unroll
-            for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(An[m], B[0][m], Dn);
-          }
-          if (b == (NB >= 2 ? NB - 2 : 0)) {
-            w = wn;
-            wn = tr[2 * (size_t)min(j + 64 + c, last)];
-            An[0] = expand_bits<FMT>(w.x);
-            An[1] = expand_bits<FMT>(w.y);
-            An[2] = expand_bits<FMT>(w.z);
-            An[3] = expand_bits<FMT>(w.w);
-          }
-          asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the test below (and their result in VGPRs)
-          // x[i] as integers: D' is a positive float, its bit pattern orders like its value
-          int x[16];
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[b + 1][m], Dn);
+        } else {
 #pragma unroll
-          for (int i = 0; i < 16; i++) {
-            x[i] = __float_as_int(D[i]);
-            if (decltype(masked)::value) {
-              const u32 off = (u32)((i & 3) + 8 * (i >> 2));
-              x[i] = (any_row && off < left) ? x[i] : 0x41000000;  // 8.0: rows past the end are farther than anything
-            }
-          }
-          // smallest element of the lane: five triples and the sixteenth element
-          int m1;
-          {
-            const int l0 = min3i(x[0], x[1], x[2]), l1 = min3i(x[3], x[4], x[5]), l2 = min3i(x[6], x[7], x[8]);
-            const int l3 = min3i(x[9], x[10], x[11]), l4 = min3i(x[12], x[13], x[14]);
-            m1 = min(min3i(l0, l1, l2), min3i(l3, l4, x[15]));
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (__builtin_expect(__builtin_amdgcn_ballot_w64(m1 < __float_as_int(second[b])) != 0, 0)) {
-            slow_steps++;
-            // Some lane has an element below its second best: the two smallest of the sixteen by
-            // a tournament (the median of a triple is its second smallest, and the second
-            // smallest of all is the second smallest of the triples' minima or one of their
-            // medians), then merged into (best, second).  Everything is recomputed from the
-            // sixteen results here: values kept alive across the branch cost registers in the
-            // common path.
-            auto med3 = [](int p, int q, int r) {
-              return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
-            };
-            int xx[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-              xx[i] = x[i];
-            }
-            int lo[5], mid[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-              lo[k] = min3i(xx[3 * k], xx[3 * k + 1], xx[3 * k + 2]);
-              mid[k] = med3(xx[3 * k], xx[3 * k + 1], xx[3 * k + 2]);
-            }
-            const int a1 = min3i(lo[0], lo[1], lo[2]), b1 = min3i(lo[3], lo[4], xx[15]);
-            const int a2 = med3(lo[0], lo[1], lo[2]), b2 = med3(lo[3], lo[4], xx[15]);
-            const int mm1 = min(a1, b1);
-            const int sl = min3i(max(a1, b1), a2, b2);
-            const int m2 = min(min3i(mid[0], mid[1], mid[2]), min3i(mid[3], mid[4], sl));
-            const int ob = __float_as_int(best[b]), os = __float_as_int(second[b]);
-            const int nb = min(ob, mm1 | (int)step);
-            const int ns = min3i(max(ob & ~1023, mm1), os, m2);
-            best[b] = __int_as_float(nb);
-            second[b] = __int_as_float(ns);
-          }
-          D = Dn;
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(An[m], B[0][m], Dn);
         }
+        if (b == (NB >= 2 ? NB - 2 : 0)) {
+          w = wn;
+          wn = tr[2 * (size_t)min(j + 64 + c, last)];
+          An[0] = expand_bits<FMT>(w.x);
+          An[1] = expand_bits<FMT>(w.y);
+          An[2] = expand_bits<FMT>(w.z);
+          An[3] = expand_bits<FMT>(w.w);
+        }
+        asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the test below (and their result in VGPRs)
+        // x[i] as integers: D' is a positive float, its bit pattern orders like its value
+        int x[16];
 #pragma unroll
-        for (int m = 0; m < 4; m++) A[m] = An[m];
-      };
-      if (__builtin_expect(j + 32 > t1, 0)) body(std::true_type{});
-      else body(std::false_type{});
+        for (int i = 0; i < 16; i++) x[i] = __float_as_int(D[i]);
+        // smallest element of the lane: five triples and the sixteenth element
+        int m1;
+        {
+          const int l0 = min3i(x[0], x[1], x[2]), l1 = min3i(x[3], x[4], x[5]), l2 = min3i(x[6], x[7], x[8]);
+          const int l3 = min3i(x[9], x[10], x[11]), l4 = min3i(x[12], x[13], x[14]);
+          m1 = min(min3i(l0, l1, l2), min3i(l3, l4, x[15]));
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(m1 < __float_as_int(second[b])) != 0, 0)) {
+          // Some lane has an element below its second best: the two smallest of the sixteen by
+          // a tournament (the median of a triple is its second smallest, and the second
+          // smallest of all is the second smallest of the triples' minima or one of their
+          // medians), then merged into (best, second).  Everything is recomputed from the
+          // sixteen results there: values kept alive across the branch cost registers in the
+          // common path.
+          slow_steps++;
+          tournament(x, b, step);
+        }
+        D = Dn;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) A[m] = An[m];
+    }
+    // The last, partial step of a range (once per scan, not pipelined; a second, masked copy of
+    // the pipelined body cost 40 registers and a wave per SIMD): D holds its block 0, A its
+    // operands; rows past the end are replaced by 8.0, farther than anything.
+    if (j < t1) {
+      const u32 left = t1 - j - 4 * h;      // the lane's rows at offsets < left exist ...
+      const bool any_row = j + 4 * h < t1;  // ... if any does
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        int x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const u32 off = (u32)((i & 3) + 8 * (i >> 2));
+          x[i] = (any_row && off < left) ? __float_as_int(D[i]) : 0x41000000;
+        }
+        tournament(x, b, step);
+        if (b + 1 < NB) {
+          D = zero;
+#pragma unroll
+          for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[b + 1][m], D);
+        }
+      }
     }
   }
 
