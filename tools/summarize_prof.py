@@ -44,11 +44,15 @@ print(open(os.path.join(dst, "pmc_counters.txt")).read())
 # HBM traffic of the dominant kernel per image pair, for bench.py's roofline.traffic
 import json
 vals = {}
-for d, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    p = os.path.join(src, d, "p_results.db")
-    r = q(p, "select kernel_name, avg(value) from counters_collection where counter_name='%s' and "
-             "kernel_name like '%%scan_kernel%%' group by kernel_name order by avg(value) desc" % ctr)
-    kname, vals[ctr] = r[0][0].split("(")[0].replace("void vsm::", ""), r[0][1]
+# the dominant kernel = the scan kernel with the largest summed FETCH_SIZE; WRITE_SIZE of the same kernel
+r = q(os.path.join(src, "pmc_fetch", "p_results.db"),
+      "select kernel_name, avg(value) from counters_collection where counter_name='FETCH_SIZE' and "
+      "kernel_name like '%scan_kernel%' group by kernel_name order by sum(value) desc")
+full_name, vals["FETCH_SIZE"] = r[0]
+kname = full_name.split("(")[0].replace("void vsm::", "")
+r = q(os.path.join(src, "pmc_write", "p_results.db"),
+      "select kernel_name, avg(value) from counters_collection where counter_name='WRITE_SIZE' group by kernel_name")
+vals["WRITE_SIZE"] = [v for n, v in r if n == full_name][0]
 pairs = 16384
 json.dump({"kernel": kname, "pairs_per_launch": pairs,
            "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
