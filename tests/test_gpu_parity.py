@@ -98,6 +98,25 @@ def _real_like_database(n_img, n_desc, seed):
     return db, (np.arange(n_img + 1) * n_desc).astype(np.uint32)
 
 
+@pytest.mark.parametrize("variant", [0xE00008, 0x10E00008, 0x20E00008, 0xE00308, 0xD00008, 0xE00001, 0xD00001])
+def test_real_descriptors_every_tail_length(m, variant):
+    """Real ORB descriptors (many near neighbours: the slow paths run in nearly every step) at
+    train sizes around the 32-row step of the matrix-core scan -- the partial last step is handled
+    apart from the pipelined loop -- under both tracking forms; also raw 2-NN."""
+    real = np.concatenate(cases.ex3())
+    noisy = real ^ cases.synth.flip_masks(len(real), 3, 77, levels=(5, 6))
+    m.set_variant(variant)
+    try:
+        for n1, n2 in [(200, 1), (200, 31), (200, 32), (200, 33), (150, 63), (150, 64), (150, 65), (97, 95), (64, 96),
+                       (33, 127), (1084, 1000), (1000, 1084), (5, 1084)]:
+            d1, d2 = real[:n1], noisy[len(noisy) - n2:]
+            assert np.array_equal(m.match(d1, d2, 70, 1.2), binding.port().match(d1, d2, 70, 1.2)), (hex(variant), n1, n2)
+            for g, w in zip(m.nn2(d1, d2), binding.port().nn2(d1, d2)):
+                assert np.array_equal(g, w), (hex(variant), n1, n2)
+    finally:
+        m.set_variant(0)
+
+
 def test_tracking_form_follows_the_data_and_never_changes_the_lists():
     """The matrix-core forward scan has two tracking forms (mfma_scan.h); the context picks one
     after every batched call from the share of steps that left the common path.  Real-like
