@@ -415,23 +415,23 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
       const u32x4 qa = qp[0], qb = qp[1];
       const u32 base = t0 + 32 * (mine ? my_step : 0u) + 4 * h;
       const u32x4* tp = tbase + 2 * (size_t)job.t_off;
-      // four consecutive rows (128 contiguous bytes) per iteration, all eight loads in flight
-      // together; descending, so that the lowest row is assigned last and wins
+      // two groups of four consecutive rows (2 x 128 contiguous bytes) per iteration, all sixteen
+      // loads in flight together; descending, so that the lowest row is assigned last and wins
 #pragma unroll 1
-      for (int g = 3; g >= 0; g--) {
-        const u32 r0 = base + 8 * (u32)g;
-        u32x4 ta[4], tb[4];
+      for (int g = 1; g >= 0; g--) {
+        u32x4 ta[8], tb[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u32 rc = min(r0 + k, t1 - 1);
+        for (int k = 0; k < 8; k++) {
+          const u32 rc = min(base + 16 * (u32)g + 8 * (u32)(k >> 2) + (u32)(k & 3), t1 - 1);
           ta[k] = tp[2 * (size_t)rc];
           tb[k] = tp[2 * (size_t)rc + 1];
         }
 #pragma unroll
-        for (int k = 3; k >= 0; k--) {
+        for (int k = 7; k >= 0; k--) {
+          const u32 r = base + 16 * (u32)g + 8 * (u32)(k >> 2) + (u32)(k & 3);
           const u32 d = __popc(qa.x ^ ta[k].x) + __popc(qa.y ^ ta[k].y) + __popc(qa.z ^ ta[k].z) + __popc(qa.w ^ ta[k].w) +
                         __popc(qb.x ^ tb[k].x) + __popc(qb.y ^ tb[k].y) + __popc(qb.z ^ tb[k].z) + __popc(qb.w ^ tb[k].w);
-          if (mine && r0 + k < t1 && d == db) idx = r0 + k;
+          if (mine && r < t1 && d == db) idx = r;
         }
       }
     }
