@@ -126,7 +126,7 @@ struct vsm_ctx {
   bool uniform_tiles[4] = {false, false, false, false};
   double avg_tiles[4] = {0, 0, 0, 0};
   // work buffers
-  DevBuf stage, scratch, jobs, counts, misc, qlist, w_pairs, w_offsets, w_out;
+  DevBuf stage, scratch, jobs, counts, misc, qlist, flist, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
   DevBuf voc;          // vocabulary tree (vsm_voc_upload)
   size_t voc_nodes = 0, voc_off[6] = {0, 0, 0, 0, 0, 0};
@@ -474,6 +474,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   // fit the LDS bitmap; bit 16 of the experiment knob turns it off for A/B runs.
   const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & 0x10000);
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
+  if (prune) VSM_TRY(c->flist.reserve(chunk * stride * sizeof(u32)));
   // Backward jobs of the pruned pass scan ragged nominated lists whose lengths only the device
   // knows: fixed 64-query tiles (matrix-core scan: 32 * 2 queries per wave, 4-wave workgroups).
   // Adaptive tiles were measured here twice and do not pay: with the popcount scan a sparse
@@ -500,7 +501,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     if (prune) {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, d_comps + 1);
+                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
@@ -513,14 +514,22 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                          d_scratch, n_entries, sh.splits, (u32)split_stride);
       HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(count_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
-                       1u, (u32)split_stride, prm, d_counts);
+    if (prune)
+      hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
+                         (const u32*)c->flist.p, stride, prm, d_counts);
+    else
+      hipLaunchKernelGGL(count_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
+                         1u, (u32)split_stride, prm, d_counts);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, d_counts, n,
                        d_out_offsets, first, d_running);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, 1u,
-                       (u32)split_stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);
+    if (prune)
+      hipLaunchKernelGGL(fill_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
+                         (const u32*)c->flist.p, stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);
+    else
+      hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, 1u,
+                         (u32)split_stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);
     HIP_TRY(hipGetLastError());
   }
   struct {
@@ -626,7 +635,7 @@ void vsm_destroy(vsm_ctx* c) {
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist,
+    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist, &c->flist,
                       &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc})
       b->release();
     c->pin.release();

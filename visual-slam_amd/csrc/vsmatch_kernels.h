@@ -601,27 +601,45 @@ __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
 // Exact: every backward result the consumer kernels read is computed.
 // Needs stride <= NOMINATE_MAX_STRIDE (LDS bitmap) and splits == 1.
 constexpr u32 NOMINATE_MAX_STRIDE = 65536;
+// It also writes the forward-accepted rows i, ascending, to flist[p*stride ...) and their number
+// to jobs[p].pad1: count_list_kernel / fill_list_kernel then read those few rows instead of
+// every row's result (three kernels each read all 8 B x N results of every pair: 130 us each per
+// 32768 pairs of 2000 descriptors, HBM-bound).
 __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
                                                        const uint2* __restrict__ scratch,
                                                        AcceptParams prm, u32 stride,
                                                        u32* __restrict__ qlist,
+                                                       u32* __restrict__ flist,
                                                        u64* __restrict__ comps) {
   __shared__ uint16_t lut[260];
   __shared__ u32 bitmap[NOMINATE_MAX_STRIDE / 32];
   __shared__ u32 wave_cnt[4];
   load_lut(lut, prm);
   const u32 p = blockIdx.x;
-  const Job f = jobs[p];
+  Job f = jobs[p];
   Job b = jobs[gridDim.x + p];
   const u32 n2 = b.nq, words = (n2 + 31) / 32;
   for (u32 w = threadIdx.x; w < words; w += 256) bitmap[w] = 0;
   __syncthreads();
-  for (u32 i = threadIdx.x; i < f.nq; i += 256) {
-    u32 j;
-    if (accepted(scratch[f.out_off + i], lut, prm.threshold, j)) atomicOr(&bitmap[j >> 5], 1u << (j & 31));
-  }
-  __syncthreads();
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 acc = 0;
+  for (u32 base = 0; base < f.nq; base += 256) {
+    const u32 i = base + threadIdx.x;
+    u32 j = 0;
+    const bool hit = i < f.nq && accepted(scratch[f.out_off + i], lut, prm.threshold, j);
+    if (hit) atomicOr(&bitmap[j >> 5], 1u << (j & 31));
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = acc, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
+    }
+    if (hit) flist[(size_t)p * stride + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    acc += all;
+    __syncthreads();
+  }
   u32 done = 0;
   for (u32 base = 0; base < n2; base += 256) {
     const u32 j = base + threadIdx.x;
@@ -639,10 +657,82 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    f.pad1 = acc;
+    jobs[p] = f;
     b.nq = done;
     b.qlist_off = p * stride;
     jobs[gridDim.x + p] = b;
     if (done && b.nt) atomicAdd((unsigned long long*)comps, (unsigned long long)done * b.nt);
+  }
+}
+
+// Cross-check of forward-accepted row flist[k] of pair p (the forward accept test was applied by
+// nominate_kernel): its backward result must be accepted and point back at it.
+__device__ __forceinline__ bool cross_check_listed(const uint2* __restrict__ scratch, const Job& f, const Job& b,
+                                                   u32 i, const uint16_t* lut, int threshold, u32& j) {
+  j = scratch[f.out_off + i].x & IDX_MASK;
+  u32 back;
+  return accepted(scratch[b.out_off + j], lut, threshold, back) && back == i;
+}
+
+// count_kernel / fill_kernel over the forward-accepted rows only (pruned path, unsplit scans).
+__global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__ jobs,
+                                                         const uint2* __restrict__ scratch,
+                                                         const u32* __restrict__ flist, u32 stride,
+                                                         AcceptParams prm, u32* __restrict__ counts) {
+  __shared__ uint16_t lut[260];
+  __shared__ u32 total;
+  if (threadIdx.x == 0) total = 0;
+  load_lut(lut, prm);
+  const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
+  const u32* list = flist + (size_t)blockIdx.x * stride;
+  u32 mine = 0;
+  for (u32 k = threadIdx.x; k < f.pad1; k += blockDim.x) {
+    u32 j;
+    mine += cross_check_listed(scratch, f, b, list[k], lut, prm.threshold, j) ? 1u : 0u;
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void fill_list_kernel(const Job* __restrict__ jobs,
+                                                        const uint2* __restrict__ scratch,
+                                                        const u32* __restrict__ flist, u32 stride,
+                                                        AcceptParams prm, const u64* __restrict__ offsets,
+                                                        u64 first, int2* __restrict__ out_pairs, u64 cap_pairs) {
+  __shared__ uint16_t lut[260];
+  __shared__ u32 wave_cnt[4];
+  load_lut(lut, prm);
+  const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
+  const u64 o0 = offsets[first + blockIdx.x];
+  if (offsets[first + blockIdx.x + 1] == o0) return;  // uniform: nothing to write
+  const u32* list = flist + (size_t)blockIdx.x * stride;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32 done = 0;
+  for (u32 base = 0; base < f.pad1; base += 256) {
+    const u32 k = base + threadIdx.x;
+    u32 i = 0, j = 0;
+    bool hit = false;
+    if (k < f.pad1) {
+      i = list[k];
+      hit = cross_check_listed(scratch, f, b, i, lut, prm.threshold, j);
+    }
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = done, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
+    }
+    if (hit) {
+      const u64 pos = o0 + before + (u32)__popcll(m & ((1ull << lane) - 1ull));
+      if (pos < cap_pairs) out_pairs[pos] = make_int2((int)i, (int)j);
+    }
+    done += all;
+    __syncthreads();
   }
 }
 
