@@ -463,15 +463,19 @@ __global__ __launch_bounds__(256) void count_kernel(const Job* __restrict__ jobs
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict__ counts, u32 n,
                                                            u64* __restrict__ offsets, u64 first,
                                                            u64* __restrict__ running) {
+  // 4096 counts per round: every thread takes four consecutive ones (coalesced 16-byte loads).
   __shared__ u64 wave_sum[16];
   __shared__ u64 carry;
   if (threadIdx.x == 0) carry = *running;
   __syncthreads();
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (u32 base = 0; base < n; base += 1024) {
-    const u32 k = base + threadIdx.x;
-    const u64 v = k < n ? counts[k] : 0;
-    u64 inc = v;
+  for (u32 base = 0; base < n; base += 4096) {
+    const u32 k = base + 4 * threadIdx.x;
+    u32 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] = k + e < n ? counts[k + e] : 0u;
+    const u64 sum = (u64)v[0] + v[1] + v[2] + v[3];
+    u64 inc = sum;
     for (int o = 1; o < 64; o <<= 1) {
       const u64 up = __shfl_up(inc, o);
       if ((int)lane >= o) inc += up;
@@ -480,7 +484,12 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict
     __syncthreads();
     u64 before = carry;
     for (u32 w = 0; w < wave; w++) before += wave_sum[w];
-    if (k < n) offsets[first + k] = before + inc - v;
+    u64 run = before + inc - sum;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (k + e < n) offsets[first + k + e] = run;
+      run += v[e];
+    }
     __syncthreads();
     if (threadIdx.x == 1023) carry = before + inc;
     __syncthreads();
