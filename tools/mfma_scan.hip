@@ -87,11 +87,11 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0));
       const dim3 g(groups * 8 * tiles), blk(64);
 #define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
-      if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr);
-      else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr);
-      else if (v.nb == 8) mfma_scan_kernel<4, 8, 1, 1><<<g, blk>>>(ARGS, nullptr);
-      else if (v.nb == 4) mfma_scan_kernel<4, 4, 1, 1><<<g, blk>>>(ARGS, nullptr);
-      else mfma_scan_kernel<4, 2, 1, 1><<<g, blk>>>(ARGS, nullptr);
+      if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else if (v.nb == 8) mfma_scan_kernel<4, 8, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else if (v.nb == 4) mfma_scan_kernel<4, 4, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else mfma_scan_kernel<4, 2, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());

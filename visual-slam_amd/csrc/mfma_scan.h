@@ -102,6 +102,25 @@ __device__ __forceinline__ void count_steps(unsigned long long* stats, u32 lane,
   }
 }
 
+// Forward scans of the batched, pruned path (unsplit, no query list): the accept test of
+// keypoints.h:295-296 on the finished (best, second) of the 32 queries of a block, one bit per
+// query, stored as word (first query of the block) / 32 of the pair's mask.  nominate_kernel then
+// reads 4 bytes per 32 queries instead of every 8-byte result (524 MB per 32768 pairs of 2000
+// descriptors, 170 us).  `acc.mask` null: not wanted.
+struct AcceptMask {
+  const uint16_t* lut;  // AcceptParams::min_second on the device
+  int threshold;
+  u32* mask;
+};
+__device__ __forceinline__ void store_accept_mask(const AcceptMask& acc, const Job& job, u32 lane, u32 q_first,
+                                                  bool valid, u32 kb, u32 ks) {
+  if (!acc.mask) return;
+  const u32 d = kb >> IDX_BITS, sd = min(ks >> IDX_BITS, 256u);
+  const bool hit = valid && d < 256u && (int)d < acc.threshold && sd >= (u32)acc.lut[min(d, 256u)];
+  const u64 m = __ballot(hit);
+  if (lane == 0) acc.mask[(job.out_off >> 6) + (q_first >> 5)] = (u32)m;  // valid only in lanes 0..31
+}
+
 // One tile = 32 * NB queries of a job (lane l: column l & 31 of each block of 32, half l >> 5 of
 // the k range) against the split's share of the train range, 32 rows at a time.
 template <int NB, int FMT>
@@ -109,7 +128,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
                                                const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
                                                u32 split_stride, uint2* __restrict__ scratch,
                                                const u32* __restrict__ qlist, u32 d_lim,
-                                               unsigned long long* __restrict__ stats) {
+                                               unsigned long long* __restrict__ stats, const AcceptMask& acc) {
   const u32 per = (job.nt + splits - 1) / splits;
   const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
   const u32 c = lane & 31, h = lane >> 5;
@@ -220,8 +239,9 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
     const float mb = fminf(best[b], ob);
     const float ms = fminf(fminf(second[b], os), fmaxf(best[b], ob));
     const u32 qi = q0 + b * 32 + c;
-    if (h == 0 && qi < job.nq)
-      out[col[b]] = make_uint2(fkey_to_key(__float_as_uint(mb), t0), fkey_to_key(__float_as_uint(ms), t0));
+    const u32 kb = fkey_to_key(__float_as_uint(mb), t0), ks = fkey_to_key(__float_as_uint(ms), t0);
+    if (h == 0 && qi < job.nq) out[col[b]] = make_uint2(kb, ks);
+    store_accept_mask(acc, job, lane, q0 + b * 32, h == 0 && qi < job.nq, kb, ks);
   }
 }
 
@@ -248,7 +268,7 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
                                                  const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
                                                  u32 split_stride, uint2* __restrict__ scratch,
                                                  const u32* __restrict__ qlist, u32 d_lim,
-                                                 unsigned long long* __restrict__ stats) {
+                                                 unsigned long long* __restrict__ stats, const AcceptMask& acc) {
   const u32 per = (job.nt + splits - 1) / splits;
   const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
   const u32 c = lane & 31, h = lane >> 5;
@@ -436,11 +456,10 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
       }
     }
     const u32 fidx = min(idx, (u32)__shfl_xor((int)idx, 32));
-    if (h == 0 && qi < job.nq) {
-      const u32 kb = fb < dlim ? ((db << IDX_BITS) | fidx) : sentinel;
-      const u32 ks = fs < dlim ? (ds << IDX_BITS) : sentinel;
-      out[colb] = make_uint2(kb, ks);
-    }
+    const u32 kb = fb < dlim ? ((db << IDX_BITS) | fidx) : sentinel;
+    const u32 ks = fs < dlim ? (ds << IDX_BITS) : sentinel;
+    if (h == 0 && qi < job.nq) out[colb] = make_uint2(kb, ks);
+    store_accept_mask(acc, job, lane, q0e + b * 32, h == 0 && qi < job.nq, kb, ks);
   }
 }
 
@@ -454,7 +473,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
                                                                const Job* __restrict__ jobs, u32 n_jobs, u32 splits,
                                                                u32 split_stride, uint2* __restrict__ scratch,
                                                                const u32* __restrict__ qlist, u32 tiles_per_job,
-                                                               u32 d_lim, unsigned long long* __restrict__ stats) {
+                                                               u32 d_lim, unsigned long long* __restrict__ stats,
+                                                               AcceptMask acc) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   u32 job_id, t;
@@ -473,23 +493,23 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
   constexpr u32 RMAX = NBMAX / 2;  // tiles are counted in units of 64 queries, as adaptive_tiles does
   const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
   if (t < full) {
-    if (TRACK) mfma_scan_tile_d<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
-    else mfma_scan_tile<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+    if (TRACK) mfma_scan_tile_d<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
+    else mfma_scan_tile<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
     return;
   }
   u32 k = t - full, q0 = full * 64 * RMAX;
   if (RMAX > 2 && (rem & 2)) {
     if (k == 0) {
-      if (TRACK) mfma_scan_tile_d<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
-      else mfma_scan_tile<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+      if (TRACK) mfma_scan_tile_d<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
+      else mfma_scan_tile<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
       return;
     }
     k--;
     q0 += 128;
   }
   if ((rem & 1) && k == 0) {
-    if (TRACK) mfma_scan_tile_d<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
-    else mfma_scan_tile<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats);
+    if (TRACK) mfma_scan_tile_d<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
+    else mfma_scan_tile<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
   }
 }
 

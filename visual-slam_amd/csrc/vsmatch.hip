@@ -126,7 +126,7 @@ struct vsm_ctx {
   bool uniform_tiles[4] = {false, false, false, false};
   double avg_tiles[4] = {0, 0, 0, 0};
   // work buffers
-  DevBuf stage, scratch, jobs, counts, misc, qlist, flist, w_pairs, w_offsets, w_out;
+  DevBuf stage, scratch, jobs, counts, misc, qlist, flist, accmask, lut, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
   DevBuf voc;          // vocabulary tree (vsm_voc_upload)
   size_t voc_nodes = 0, voc_off[6] = {0, 0, 0, 0, 0, 0};
@@ -324,7 +324,8 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
                 const u32* d_qlist = nullptr, u32 d_lim = 256, unsigned long long* d_stats = nullptr,
-                int track = -1) {  // tracking form: 1 distances, 0 keys, -1 the context's current choice
+                int track = -1,  // tracking form: 1 distances, 0 keys, -1 the context's current choice
+                AcceptMask acc = AcceptMask{nullptr, 0, nullptr}) {
   const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
   const u64 blocks = n_jobs * sh.wgs_per_job;
@@ -365,10 +366,10 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
                      sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
 #define VSM_LAUNCH_M(NN)                                                                               \
   hipLaunchKernelGGL((mfma_scan_kernel<4, NN>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats)
+                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats, acc)
 #define VSM_LAUNCH_MD(NN)                                                                              \
   hipLaunchKernelGGL((mfma_scan_kernel<4, NN, 1, 1>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats)
+                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats, acc)
     // Tracking form: the context's current choice (see scan_track); knob nibble 20-23 = 14 / 13
     // forces distances / keys everywhere, 12 = distances in forward scans, keys elsewhere.
     const int vtr = (c->variant >> 20) & 0xf;
@@ -408,10 +409,10 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
     // keys (the index recovery of the distance form costs it 3 us of 56)
     if (vtr == 14 || (vtr != 13 && vtr != 12 && (track >= 0 ? track == 1 : (d_qlist && c->scan_track == 1))))
       hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4, 1>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
-                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr);
+                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr, AcceptMask{nullptr, 0, nullptr});
     else
       hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
-                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr);
+                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr, AcceptMask{nullptr, 0, nullptr});
   } else
   // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
   switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
@@ -475,6 +476,16 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & 0x10000);
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
   if (prune) VSM_TRY(c->flist.reserve(chunk * stride * sizeof(u32)));
+  // accept masks (one bit per forward row) and the accept table on the device, for the matrix-core
+  // forward scan's epilogue; the popcount scans do not write masks (nominate_kernel then reads every row)
+  const bool masks = prune && sh.mfma && sh.adaptive && !(c->variant & 0x1000000);
+  AcceptMask acc{nullptr, 0, nullptr};
+  if (masks) {
+    VSM_TRY(c->accmask.reserve(chunk * (stride / 32) * sizeof(u32)));
+    VSM_TRY(c->lut.reserve(sizeof prm.min_second));
+    HIP_TRY(hipMemcpyAsync(c->lut.p, prm.min_second, sizeof prm.min_second, hipMemcpyHostToDevice, c->stream));
+    acc = AcceptMask{(const uint16_t*)c->lut.p, prm.threshold, (u32*)c->accmask.p};
+  }
   // Backward jobs of the pruned pass scan ragged nominated lists whose lengths only the device
   // knows: fixed 64-query tiles (matrix-core scan: 32 * 2 queries per wave, 4-wave workgroups).
   // Adaptive tiles were measured here twice and do not pay: with the popcount scan a sparse
@@ -499,9 +510,9 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        prune ? 1u : 2u);
     HIP_TRY(hipGetLastError());
     if (prune) {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats));
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats, -1, acc));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1);
+                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1, (const u32*)acc.mask);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
@@ -635,7 +646,7 @@ void vsm_destroy(vsm_ctx* c) {
     DeviceGuard g(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist, &c->flist,
+    for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist, &c->flist, &c->accmask, &c->lut,
                       &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc})
       b->release();
     c->pin.release();

@@ -619,7 +619,8 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
                                                        AcceptParams prm, u32 stride,
                                                        u32* __restrict__ qlist,
                                                        u32* __restrict__ flist,
-                                                       u64* __restrict__ comps) {
+                                                       u64* __restrict__ comps,
+                                                       const u32* __restrict__ accmask) {
   __shared__ uint16_t lut[260];
   __shared__ u32 bitmap[NOMINATE_MAX_STRIDE / 32];
   __shared__ u32 wave_cnt[4];
@@ -632,6 +633,39 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   __syncthreads();
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 acc = 0;
+  if (accmask) {
+    // the matrix-core forward scan left one accept bit per row (mfma_scan.h store_accept_mask):
+    // a thread takes a 32-row word, an exclusive prefix over the words gives its list position
+    const u32 nw = (f.nq + 31) / 32;
+    const u32* mw = accmask + (f.out_off >> 6);
+    for (u32 base = 0; base < nw; base += 256) {
+      const u32 w = base + threadIdx.x;
+      u32 bits = w < nw ? mw[w] : 0u;
+      const u32 cnt = (u32)__popc(bits);
+      u32 inc = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 up = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += up;
+      }
+      if (lane == 63) wave_cnt[wave] = inc;
+      __syncthreads();
+      u32 before = acc, all = 0;
+      for (u32 k = 0; k < 4; k++) {
+        if (k < wave) before += wave_cnt[k];
+        all += wave_cnt[k];
+      }
+      u32 pos = before + inc - cnt;
+      while (bits) {
+        const u32 i = w * 32 + (u32)__builtin_ctz(bits);
+        bits &= bits - 1;
+        flist[(size_t)p * stride + pos++] = i;
+        const u32 j = scratch[f.out_off + i].x & IDX_MASK;
+        atomicOr(&bitmap[j >> 5], 1u << (j & 31));
+      }
+      acc += all;
+      __syncthreads();
+    }
+  } else
   for (u32 base = 0; base < f.nq; base += 256) {
     const u32 i = base + threadIdx.x;
     u32 j = 0;
@@ -649,6 +683,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
     acc += all;
     __syncthreads();
   }
+  __syncthreads();
   u32 done = 0;
   for (u32 base = 0; base < n2; base += 256) {
     const u32 j = base + threadIdx.x;
