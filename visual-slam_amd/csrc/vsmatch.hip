@@ -490,7 +490,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   // knows: fixed 64-query tiles (matrix-core scan: 32 * 2 queries per wave, 4-wave workgroups).
   // Adaptive tiles were measured here twice and do not pay: with the popcount scan a sparse
   // batch went 0.45 -> 1.18 ms per launch and a dense one 4.4 -> 5.4 ms; with the matrix-core
-  // scan (256-query tiles) sparse 0.137 -> 0.153 ms, dense 1.59 -> 1.62 ms.
+  // scan (256-query tiles) sparse 0.137 -> 0.153 ms, dense 1.59 -> 1.62 ms.  One looping workgroup
+  // per job instead of eight mostly idle ones: sparse 0.144 -> 0.172 ms, dense 1.50 -> 1.36 ms.
   ScanShape shb = sh;
   shb.adaptive = false;
   const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
