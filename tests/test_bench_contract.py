@@ -18,6 +18,13 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.5 < r["frac"] < 1.0
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 9000 < r["peak"] < 11000  # dense FP4 peak
+    # the popcount formulation of north_star, measured in the same run: lists identical, its own roofline
+    p = d["popcount_path"]
+    assert p["lists_identical_to_matrix_core_path"] is True and p["roofline"]["bound"] == "valu"
+    assert 0.7 < p["roofline"]["frac"] < 1.0 and d["pairs_per_s"] > 3 * p["pairs_per_s"]
+    x = d["extra"]["real_orb_statistics_200img_19900pairs"]
+    assert x["sample_of_24_pairs_equals_cpu_reference"] is True and x["chosen"]["tracking_form"] == "distances"
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
