@@ -37,7 +37,8 @@ d_out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
 res = {"images": n_img, "desc_per_image": n_desc, "pairs": int(len(pairs))}
 lists = {}
 for name, variant in (("matrix_core_auto", 0), ("popcount", 0x2000000), ("matrix_core_distances", 0xE00000), ("matrix_core_keys", 0xD00000),
-                      ("matrix_core_distances_forward_only", 0xC00000), ("matrix_core_auto_again", 0)):
+                      ("matrix_core_distances_forward_only", 0xC00000), ("distances_128_query_tiles", 0x20E00000), ("distances_64_query_tiles", 0x10E00000),
+                      ("matrix_core_auto_again", 0)):
     m.set_variant(variant)
     m.match_pairs_device(d_pairs.data_ptr(), len(pairs), 70, 1.2, d_offs.data_ptr(), d_out.data_ptr(), cap)
     m.set_profiling(True)

@@ -265,7 +265,7 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
 // query per lane and the train range split over grid.y so that all 256 CUs work.
 ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u32* exact_max_tiles = nullptr,
                        const bool* uniform_tiles = nullptr, const double* avg_tiles = nullptr,
-                       u64 jobs_per_launch = 0) {
+                       u64 jobs_per_launch = 0, bool slow_steps = false) {
   ScanShape s;
   // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
   // override, bit 17 = integer-key tracking everywhere
@@ -293,6 +293,9 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
       return (double)(jobs_per_launch ? jobs_per_launch : n_jobs) * per_job * (double)ls;
     };
     while (s.rmax > 1 && waves_at(s.rmax) < 131072.0) s.rmax /= 2;
+    // Most steps leave the common path (real descriptors, distance form): the VALU-bound slow
+    // step likes three waves per SIMD, which the 128-query tile (142 VGPRs) allows: 8.4 -> 8.8 T.
+    if (slow_steps && s.rmax > 2) s.rmax = 2;
     const int force = (variant >> 28) & 0x7;
     if (force == 1 || force == 2 || force == 4) s.rmax = force;
   }
@@ -460,7 +463,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : nullptr,
                                     d_desc == c->db ? c->uniform_tiles : nullptr,
                                     d_desc == c->db ? c->avg_tiles : nullptr,
-                                    std::min<u64>(n_pairs, 32768));  // forward jobs of one chunk
+                                    std::min<u64>(n_pairs, 32768),  // forward jobs of one chunk
+                                    c->scan_track == 1 && c->last_slow_share > 0.5);
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
