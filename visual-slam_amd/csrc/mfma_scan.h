@@ -26,20 +26,28 @@
 // Tracking.  A lane of the 32x32 result holds 16 train rows of ONE query column, so it keeps
 // its own (best, second) per query block and the two lanes of a column are merged at the end.
 // Per block of 1024 distances the common case is eight v_min3_i32 and a compare: only if some
-// lane sees a distance at or below its current second best does the wave take the slow path
-// (float keys d * 32768 + j, v_med3_f32 / v_min_f32, as vsmatch_kernels.h FILL 5).  The start
+// lane sees a distance below its current second best does the wave leave that path.  The start
 // value of (best, second) is a key of distance `d_lim`: the matcher passes the smallest
 // distance that can no longer change the accept test (keypoints.h:295-296; accept_limit in
 // vsmatch.hip), the raw 2-NN entry point passes 256 (everything is tracked, exactly).
-// (Tried, no gain: tracking only the groups of three elements whose minimum passes the test
-// (17 more VGPRs); a branch per element in the slow path (exact mode 4.9 -> 3.9 T at NB = 8); train codes 0.0 / 1.0 instead of +-1.0 with pop(q) folded into the lane's
-// limit -- the bare instruction runs 10 % faster on half-zero operands (tools/mfma_rate.hip,
-// power), this kernel does not: 14.0 T comparisons/s either way on 32768-pair launches.)
+// Two forms of what happens off the common path, chosen by the host from how often it happens
+// (count_steps below; vsmatch.hip scan_track):
+//   * mfma_scan_tile   -- float keys d * 32768 + j, v_med3_f32 / v_min_f32 per element (as
+//     vsmatch_kernels.h FILL 5), ~90 instructions: for data on which it is rare (iid bits);
+//   * mfma_scan_tile_d -- the two smallest DISTANCES by a 12-instruction tournament, the train
+//     index recovered at the end of the scan: for real ORB descriptors, where nearly every
+//     step leaves the common path.  Described at the function.
+// (Tried on the key form, no gain: tracking only the groups of three elements whose minimum
+// passes the test (17 more VGPRs); a branch per element in the slow path (exact mode 4.9 -> 3.9 T
+// at NB = 8); train codes 0.0 / 1.0 instead of +-1.0 with pop(q) folded into the lane's limit --
+// the bare instruction runs 10 % faster on half-zero operands (tools/mfma_rate.hip, power),
+// this kernel does not: 14.0 T comparisons/s either way on 32768-pair launches.)
 //
-// Measured (tools/mfma_scan.hip, tools/mfma_rate.hip, profiles/r01): 13.6 T comparisons/s on the
-// 5000 x 2000 batch against 2.6 T for the popcount scan; the instruction alone, back to back on
-// random +-1 codes at the same two waves per SIMD, sustains 14.5 T (the chip clocks down to
-// ~1.9 GHz under it), at 2.4 GHz it would be 19.66 T.
+// Measured (tools/mfma_scan.hip, tools/mfma_rate.hip, tools/valu_beside_mfma.hip, profiles/r01):
+// 13.7 T comparisons/s on the 5000 x 2000 batch against 2.6 T for the popcount scan; the
+// instruction alone, back to back on random +-1 codes at the same two waves per SIMD, sustains
+// 14.5 T (the chip clocks down to ~1.9 GHz under it; at 2.4 GHz it would be 19.66 T), and the
+// nine VALU instructions of the common path beside it cost the remaining ~10 %.
 // Build with -mllvm -amdgpu-mfma-vgpr-form: the minimum tree reads the results with VALU
 // instructions, from AGPRs every element would first need a v_accvgpr_read.
 #pragma once
@@ -51,8 +59,8 @@ namespace vsm {
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// FMT = cbsz / blgp code of the operand format: 0 = FP8 e4m3 (8 registers per k-step),
-// 4 = FP4 e2m1 (4 registers per k-step).
+// FMT = cbsz / blgp code of the operand format: 4 = FP4 e2m1 (4 registers per k-step), what
+// ships; 0 = FP8 e4m3 (8 registers per k-step, half the MFMA rate), kept for tools/mfma_scan.hip.
 template <int FMT>
 __device__ __forceinline__ i32x8 expand_bits(u32 w) {
   i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
