@@ -323,14 +323,10 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
     auto med3 = [](int p, int q, int r) {
       return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
     };
-    auto tournament = [&](const int (&x)[16], int b, u32 step) {
-      int lo[5], mid[5];
+    auto tournament = [&](const int (&x)[16], const int (&lo)[5], int a1, int b1, int b, u32 step) {
+      int mid[5];
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        lo[k] = min3i(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
-        mid[k] = med3(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
-      }
-      const int a1 = min3i(lo[0], lo[1], lo[2]), b1 = min3i(lo[3], lo[4], x[15]);
+      for (int k = 0; k < 5; k++) mid[k] = med3(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
       const int a2 = med3(lo[0], lo[1], lo[2]), b2 = med3(lo[3], lo[4], x[15]);
       const int mm1 = min(a1, b1);
       const int sl = min3i(max(a1, b1), a2, b2);
@@ -338,6 +334,14 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
       const int ob = __float_as_int(best[b]), os = __float_as_int(second[b]);
       best[b] = __int_as_float(min(ob, mm1 | (int)step));
       second[b] = __int_as_float(min3i(max(ob & ~1023, mm1), os, m2));
+    };
+    // minima of the five triples, of the two halves, of all sixteen
+    auto minima = [&](const int (&x)[16], int (&lo)[5], int& a1, int& b1) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) lo[k] = min3i(x[3 * k], x[3 * k + 1], x[3 * k + 2]);
+      a1 = min3i(lo[0], lo[1], lo[2]);
+      b1 = min3i(lo[3], lo[4], x[15]);
+      return min(a1, b1);
     };
     u32 step = 0, j = t0;
     // Full steps of 32 train rows, software pipelined as in the key form.
@@ -366,12 +370,8 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
 #pragma unroll
         for (int i = 0; i < 16; i++) x[i] = __float_as_int(D[i]);
         // smallest element of the lane: five triples and the sixteenth element
-        int m1;
-        {
-          const int l0 = min3i(x[0], x[1], x[2]), l1 = min3i(x[3], x[4], x[5]), l2 = min3i(x[6], x[7], x[8]);
-          const int l3 = min3i(x[9], x[10], x[11]), l4 = min3i(x[12], x[13], x[14]);
-          m1 = min(min3i(l0, l1, l2), min3i(l3, l4, x[15]));
-        }
+        int lo[5], a1, b1;
+        const int m1 = minima(x, lo, a1, b1);
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -381,11 +381,9 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
           // Some lane has an element below its second best: the two smallest of the sixteen by
           // a tournament (the median of a triple is its second smallest, and the second
           // smallest of all is the second smallest of the triples' minima or one of their
-          // medians), then merged into (best, second).  Everything is recomputed from the
-          // sixteen results there: values kept alive across the branch cost registers in the
-          // common path.
+          // medians), then merged into (best, second); the triples' minima come from the test.
           slow_steps++;
-          tournament(x, b, step);
+          tournament(x, lo, a1, b1, b, step);
         }
         D = Dn;
       }
@@ -406,7 +404,9 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
           const u32 off = (u32)((i & 3) + 8 * (i >> 2));
           x[i] = (any_row && off < left) ? __float_as_int(D[i]) : 0x41000000;
         }
-        tournament(x, b, step);
+        int lo[5], a1, b1;
+        minima(x, lo, a1, b1);
+        tournament(x, lo, a1, b1, b, step);
         if (b + 1 < NB) {
           D = zero;
 #pragma unroll
