@@ -1,7 +1,9 @@
 // tools/mfma_scan.hip -- the matrix-core scan (csrc/mfma_scan.h) against the popcount scan on the
 // same jobs: bitwise comparison of the scratch results and launch times.
 //   hipcc --offload-arch=gfx950 -O3 -I visual-slam_amd/csrc tools/mfma_scan.hip -o /tmp/mfma_scan
-//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim] [plant a true match every k-th descriptor, 0 = none]
+//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim] [plant a true match every k-th descriptor, 0 = none] [real]
+// `real` as fifth argument: images are random draws from the reference's 1084 real ORB descriptors
+// (tests/golden/ex3_kd{0,1}.npy, run from the repository root) with ~8 bits flipped per copy.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -33,12 +35,57 @@ __global__ void fill_db(u32* p, u32 n_img, u32 N, u32 plant) {
   }
 }
 
+// The group form stores an upper bound of the second best distance; the library's consumers make
+// it exact with refine_second (vsmatch_kernels.h) where it matters -- here for every entry.
+__global__ void refine_all(const u32x4* db, const Job* jobs, uint2* scr) {
+  const Job job = jobs[blockIdx.x];
+  for (u32 q = threadIdx.x; q < job.nq; q += blockDim.x) {
+    const uint2 v = scr[job.out_off + q];
+    const u32 s = refine_second(db + 2 * (size_t)(job.q_off + q), db + 2 * (size_t)job.t_off, job.nt, job.nt, v);
+    scr[job.out_off + q].y = s << IDX_BITS;
+  }
+}
+
+// data of a little-endian .npy file of uint64 (version 1 header)
+static std::vector<unsigned long long> load_npy_u64(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+  unsigned char head[10];
+  if (fread(head, 1, 10, f) != 10 || memcmp(head, "\x93NUMPY", 6) != 0) { fprintf(stderr, "%s: not an npy file\n", path); exit(2); }
+  const size_t hlen = head[8] | (head[9] << 8);
+  fseek(f, 0, SEEK_END);
+  const size_t bytes = (size_t)ftell(f) - 10 - hlen;
+  fseek(f, (long)(10 + hlen), SEEK_SET);
+  std::vector<unsigned long long> v(bytes / 8);
+  if (fread(v.data(), 8, v.size(), f) != v.size()) { fprintf(stderr, "%s: short read\n", path); exit(2); }
+  fclose(f);
+  return v;
+}
+static unsigned long long sm64(unsigned long long& x) {
+  unsigned long long z = (x += 0x9e3779b97f4a7c15ull);
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
 int main(int argc, char** argv) {
   const u32 n_img = 512, N = argc > 1 ? atoi(argv[1]) : 2000, P = argc > 2 ? atoi(argv[2]) : 4096;
   const u32 d_lim = argc > 3 ? atoi(argv[3]) : 256;
   const u32 plant = argc > 4 ? atoi(argv[4]) : 4;
   u32* db;
   CK(hipMalloc(&db, (size_t)n_img * N * 32));
+  if (argc > 5 && !strcmp(argv[5], "real")) {
+    std::vector<unsigned long long> real = load_npy_u64("tests/golden/ex3_kd0.npy"), r1 = load_npy_u64("tests/golden/ex3_kd1.npy");
+    real.insert(real.end(), r1.begin(), r1.end());
+    const size_t nr = real.size() / 4;
+    std::vector<unsigned long long> h_db((size_t)n_img * N * 4);
+    unsigned long long st = 12345;
+    for (size_t i = 0; i < (size_t)n_img * N; i++) {
+      const size_t src = sm64(st) % nr;
+      for (int w = 0; w < 4; w++) h_db[4 * i + w] = real[4 * src + w] ^ (sm64(st) & sm64(st) & sm64(st) & sm64(st) & sm64(st));  // ~2 bits per word
+    }
+    CK(hipMemcpy(db, h_db.data(), h_db.size() * 8, hipMemcpyHostToDevice));
+    printf("database: random draws from %zu real ORB descriptors\n", nr);
+  } else
   fill_db<<<(u32)(((size_t)n_img * N * 8 + 255) / 256), 256>>>(db, n_img, N, plant);
   const u32 stride = (N + 63) / 64 * 64;
   std::vector<Job> jobs(2 * P);
@@ -77,8 +124,9 @@ int main(int argc, char** argv) {
   printf("N=%u pairs=%u d_lim=%u comps/launch=%.3e\n", N, P, d_lim, comps);
   printf("%-28s %8.3f ms %9.1f Gcomp/s\n", "popcount adaptive<8,1,4>", t_ref, comps / (t_ref * 1e-3) / 1e9);
 
-  struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking
-  const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2}};
+  struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
+  const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2},
+                  {"mfma group NB8", 24, 8}, {"mfma group NB4", 24, 4}, {"mfma group NB2", 24, 2}};
   for (const V& v : vs) {
     float tm = 1e30f;
     const u32 tiles = adaptive_tiles(N, v.nb / 2), groups = (n_jobs + 7) / 8;
@@ -89,6 +137,9 @@ int main(int argc, char** argv) {
 #define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
       if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else if (v.fmt == 24 && v.nb == 8) mfma_scan_kernel<4, 8, 1, 2><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else if (v.fmt == 24 && v.nb == 4) mfma_scan_kernel<4, 4, 1, 2><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+      else if (v.fmt == 24) mfma_scan_kernel<4, 2, 1, 2><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.nb == 8) mfma_scan_kernel<4, 8, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.nb == 4) mfma_scan_kernel<4, 4, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else mfma_scan_kernel<4, 2, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
@@ -97,6 +148,14 @@ int main(int argc, char** argv) {
       CK(hipGetLastError());
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
+    }
+    if (v.fmt == 24) {
+      CK(hipEventRecord(e0));
+      refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float t; CK(hipEventElapsedTime(&t, e0, e1));
+      printf("   (refine_second over EVERY entry: %.3f ms)\n", t);
     }
     CK(hipMemcpy(h.data(), scr, n_scr * sizeof(uint2), hipMemcpyDeviceToHost));
     // expected result under the limit: keys of distance >= d_lim are replaced by the start key

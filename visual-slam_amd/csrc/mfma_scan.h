@@ -75,6 +75,17 @@ __device__ __forceinline__ i32x8 expand_bits(u32 w) {
   return v;
 }
 
+// The same FP4 expansion with the two masks in REGISTERS (0x88888888 in an SGPR, 0x22222222 in a
+// VGPR): gfx950's three-operand encoding takes no literal, so with literal masks the compiler emits
+// v_and + v_or per register (44 instructions per 32 train rows with the shifts); from registers it
+// is one v_and_or_b32 (28).
+__device__ __forceinline__ i32x8 expand_bits_r(u32 w, u32 m88, u32 c22) {
+  i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < 4; s++) v[s] = (int)(((w << s) & m88) | c22);
+  return v;
+}
+
 template <int FMT>
 __device__ __forceinline__ f32x16 mfma_step(const i32x8 a, const i32x8 b, const f32x16 c) {
   // block scales (e8m0): A x 2^0, B x 2^-7, so that a product is +-1/128 and the accumulator,
@@ -472,6 +483,173 @@ __device__ __forceinline__ void mfma_scan_tile_d(const u32x4* __restrict__ qbase
   }
 }
 
+// ---- Group tracking (TRACK 2): no branch, eleven instructions per step, no index recovery ----
+// Both forms above pay for a wave-level skip test that real descriptors defeat: a running minimum
+// over the 62 steps of a 2000-row scan improves ~5 times per lane, a wave has 64 lanes, so some
+// lane has news in nearly every step and the whole wave leaves the common path (92 % of the steps
+// on the real-like database, 8.6 T comparisons/s).  This tile does the same work in EVERY step and
+// makes that work small.
+//  * The accumulators start from sixteen REGISTERS, element i at 6.0 + i ulp, instead of the
+//    inline constant: D'[i] = 4 + d / 64 + i * 2^-21.  All of [4, 8) is one binade, so the bit
+//    pattern of a result is 0x40800000 | d << 15 | i: the distance in bits 15-22, the element
+//    number -- which orders like the train row, (i & 3) + 8 (i >> 2) + 4 h -- in bits 0-3, every
+//    partial sum a multiple of 2^-21 below 8, exact in f32.  The eight v_min3 that find the
+//    smallest of a lane's sixteen results now find (distance, lowest row) at once.
+//  * A lane's sixteen results of a step are a GROUP; the lane keeps the two smallest group
+//    minima: second = med3(best, m, second), best = min(best, m | step << 4) -- three more
+//    instructions, no compare, no branch; `best` orders like (distance, step, row), i.e. like the
+//    reference's strict '<' in an ascending scan (keypoints.h:273), and its train index is read off
+//    its bits at the end.
+//  * What this leaves out: the second smallest of ALL values is either the second smallest group
+//    minimum -- tracked here -- or the second smallest value INSIDE the best's group (any other
+//    group contributes at most its minimum).  The scan therefore stores an upper bound of the
+//    second best distance that is exact unless the true one sits in the 32-row step of the best;
+//    the consumers (refine_second, vsmatch_kernels.h) look at those 32 rows again with v_xor /
+//    v_bcnt -- and only for queries the accept test would otherwise pass, a few per image pair.
+// Tag bits make `best` / `second` up to 2^14 units in the last place larger than the pure D'; a
+// distance unit is 2^15, so order between different distances is untouched.
+constexpr int GROUP_D_BASE = 0x40800000;  // bits of 4.0 = D' of distance 0
+constexpr int GROUP_D_256 = 0x41000000;   // bits of 8.0 = D' of distance 256
+template <int NB, int FMT>
+__device__ __forceinline__ void mfma_scan_tile_g(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
+                                                 const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
+                                                 u32 split_stride, uint2* __restrict__ scratch,
+                                                 const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
+  const u32 per = (job.nt + splits - 1) / splits;
+  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
+  const u32 c = lane & 31, h = lane >> 5;
+
+  u32 m88 = 0x88888888u, c22 = 0x22222222u;
+  asm volatile("" : "+s"(m88), "+v"(c22));
+  i32x8 B[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const u32 qi = min(q0 + b * 32 + c, job.nq - 1);
+    const u32 colb = job.qlist_off != NO_QLIST ? qlist[job.qlist_off + qi] : qi;
+    const u32x4 w = qbase[2 * (size_t)(job.q_off + colb) + h];
+    B[b][0] = expand_bits_r(~w.x, m88, c22);
+    B[b][1] = expand_bits_r(~w.y, m88, c22);
+    B[b][2] = expand_bits_r(~w.z, m88, c22);
+    B[b][3] = expand_bits_r(~w.w, m88, c22);
+  }
+  const int init = d_lim >= 256u ? GROUP_D_256 : GROUP_D_BASE | (int)(d_lim << 15);
+  int best[NB], second[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) best[b] = second[b] = init;
+
+  if (t1 > t0) {
+    const u32x4* tr = tbase + 2 * (size_t)job.t_off + h;
+    const u32 last = t1 - 1;
+    // start values of the accumulators: 6.0 + i ulp, kept in registers for the whole scan
+    f32x16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; i++) zero[i] = __int_as_float(0x40C00000 + i);
+    asm volatile("" : "+v"(zero));
+    u32x4 w = tr[2 * (size_t)min(t0 + c, last)];
+    u32x4 wn = tr[2 * (size_t)min(t0 + 32 + c, last)];
+    i32x8 A[4];
+    A[0] = expand_bits_r(w.x, m88, c22);
+    A[1] = expand_bits_r(w.y, m88, c22);
+    A[2] = expand_bits_r(w.z, m88, c22);
+    A[3] = expand_bits_r(w.w, m88, c22);
+    f32x16 D = zero;
+#pragma unroll
+    for (int m = 0; m < 4; m++) D = mfma_step<FMT>(A[m], B[0][m], D);
+    i32x8 An[4] = {A[0], A[1], A[2], A[3]};
+    auto med3 = [](int p, int q, int r) {
+      return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
+    };
+    // group minimum: five triples and the sixteenth element
+    auto group_min = [](const int (&x)[16]) {
+      const int m0 = min3i(x[0], x[1], x[2]), m1 = min3i(x[3], x[4], x[5]), m2 = min3i(x[6], x[7], x[8]);
+      const int m3 = min3i(x[9], x[10], x[11]), m4 = min3i(x[12], x[13], x[14]);
+      return min(min3i(m0, m1, m2), min3i(m3, m4, x[15]));
+    };
+    u32 step16 = 0, j = t0;  // step16 = 16 x the number of the 32-row step
+    for (; j + 32 <= t1; j += 32, step16 += 16) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        f32x16 Dn = zero;
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(A[m], B[b + 1][m], Dn);
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; m++) Dn = mfma_step<FMT>(An[m], B[0][m], Dn);
+        }
+        if (b == (NB >= 2 ? NB - 2 : 0)) {
+          w = wn;
+          wn = tr[2 * (size_t)min(j + 64 + c, last)];
+          An[0] = expand_bits_r(w.x, m88, c22);
+          An[1] = expand_bits_r(w.y, m88, c22);
+          An[2] = expand_bits_r(w.z, m88, c22);
+          An[3] = expand_bits_r(w.w, m88, c22);
+        }
+        asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the minimum tree (and their result in VGPRs)
+        int x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = __float_as_int(D[i]);
+        const int m = group_min(x);
+        second[b] = med3(best[b], m, second[b]);
+        best[b] = min(best[b], m | (int)step16);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        D = Dn;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) A[m] = An[m];
+    }
+    // The last, partial step of a range (once per scan, not pipelined): D holds its block 0, A
+    // its operands; rows past the end are replaced by distance 256, which is never recorded.
+    if (j < t1) {
+      const u32 left = t1 - j - 4 * h;      // the lane's rows at offsets < left exist ...
+      const bool any_row = j + 4 * h < t1;  // ... if any does
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        int x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const u32 off = (u32)((i & 3) + 8 * (i >> 2));
+          x[i] = (any_row && off < left) ? __float_as_int(D[i]) : GROUP_D_256;
+        }
+        const int m = group_min(x);
+        second[b] = med3(best[b], m, second[b]);
+        best[b] = min(best[b], m | (int)step16);
+        if (b + 1 < NB) {
+          D = zero;
+#pragma unroll
+          for (int m2 = 0; m2 < 4; m2++) D = mfma_step<FMT>(A[m2], B[b + 1][m2], D);
+        }
+      }
+    }
+  }
+
+  // Epilogue (q0 laundered so that nothing of it is hoisted above the scan, see the distance form):
+  // bits -> packed keys, the two halves of the wave (same queries, disjoint rows) merged exactly.
+  u32 q0e = q0;
+  asm volatile("" : "+s"(q0e));
+  uint2* out = scratch + (size_t)split * split_stride + job.out_off;
+  const u32 sentinel = d_lim >= 256u ? KEY_INIT : ((d_lim << IDX_BITS) | t0);
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const u32 bb = (u32)best[b], sb = (u32)second[b];
+    const u32 i = bb & 15u;
+    const u32 row = t0 + 2 * ((bb >> 4) & 1023u) * 16 + 4 * h + (i & 3u) + 8 * (i >> 2);
+    const u32 kl = (int)bb < init ? ((((bb >> 15) & 255u) << IDX_BITS) | row) : sentinel;
+    const u32 sl = (int)(sb & ~32767u) < init ? (((sb >> 15) & 255u) << IDX_BITS) : sentinel;
+    const u32 ko = (u32)__shfl_xor((int)kl, 32), so = (u32)__shfl_xor((int)sl, 32);
+    const u32 kb = min(kl, ko), ks = min(min(sl, so), max(kl, ko));
+    const u32 qi = q0e + b * 32 + c;
+    const u32 qc = min(qi, job.nq - 1);
+    const u32 colb = job.qlist_off != NO_QLIST ? qlist[job.qlist_off + qc] : qc;
+    if (h == 0 && qi < job.nq) out[colb] = make_uint2(kb, ks);
+    store_accept_mask(acc, job, lane, q0e + b * 32, h == 0 && qi < job.nq, kb, ks);
+  }
+}
+
 // WAVES == 1: same grid as scan_kernel_adaptive<*, 1, *> (one-wave workgroups): tiles of
 // 32 * NBMAX queries and remainder tiles of half and a quarter of that, grouped or job-minor
 // block order.  WAVES == 4: same grid as scan_kernel (4-wave workgroups, job-minor), used with
@@ -502,14 +680,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
   constexpr u32 RMAX = NBMAX / 2;  // tiles are counted in units of 64 queries, as adaptive_tiles does
   const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
   if (t < full) {
-    if (TRACK) mfma_scan_tile_d<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
+    if (TRACK == 2) mfma_scan_tile_g<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+    else if (TRACK) mfma_scan_tile_d<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
     else mfma_scan_tile<NBMAX, FMT>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
     return;
   }
   u32 k = t - full, q0 = full * 64 * RMAX;
   if (RMAX > 2 && (rem & 2)) {
     if (k == 0) {
-      if (TRACK) mfma_scan_tile_d<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
+      if (TRACK == 2) mfma_scan_tile_g<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+      else if (TRACK) mfma_scan_tile_d<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
       else mfma_scan_tile<4, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
       return;
     }
@@ -517,7 +697,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
     q0 += 128;
   }
   if ((rem & 1) && k == 0) {
-    if (TRACK) mfma_scan_tile_d<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
+    if (TRACK == 2) mfma_scan_tile_g<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+    else if (TRACK) mfma_scan_tile_d<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
     else mfma_scan_tile<2, FMT>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, stats, acc);
   }
 }

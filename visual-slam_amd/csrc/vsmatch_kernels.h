@@ -408,6 +408,45 @@ __global__ __launch_bounds__(256) void merge_splits_kernel(uint2* __restrict__ s
   scratch[i] = v;
 }
 
+// The matrix-core scan (mfma_scan.h) stores an UPPER BOUND of the second best distance: exact
+// unless the true second best sits in the best's own GROUP -- the sixteen train rows one lane of
+// the 32 x 32 result block holds in one step of the scan: rows b0 + 4 hh + (k & 3) + 8 (k >> 2),
+// k = 0..15, with b0 = t0 + 32 * ((idx - t0) / 32), hh = ((idx - b0) >> 2) & 1 and t0 the start
+// of the train split that holds idx.  This looks at the group's other fifteen rows again: the
+// exact second best is the minimum of the stored one and of their distances (keypoints.h:273-289:
+// best and second are the two smallest of the multiset; every row outside the group is covered
+// by its own group's minimum, which the scan tracked).  `q` = the query's descriptor, `tr` = first
+// descriptor of the job's train range, `per` = rows per train split (= nt when unsplit).  Called
+// by the consumers only for results the accept test would otherwise pass (a few per image pair)
+// and by the raw 2-NN output for every query.  Idempotent, and harmless on an exact result.
+__device__ __forceinline__ u32 refine_second(const u32x4* __restrict__ q, const u32x4* __restrict__ tr, u32 nt,
+                                             u32 per, uint2 v) {
+  const u32 d = v.x >> IDX_BITS, idx = v.x & IDX_MASK;
+  u32 s = min(v.y >> IDX_BITS, 256u);
+  if (d >= 256u || s <= d || idx >= nt) return s;  // nothing found / already a tie
+  const u32 t0 = idx / per * per, t1 = min(t0 + per, nt);
+  const u32 b0 = t0 + ((idx - t0) & ~31u) + ((idx - t0) & 4u);
+  const u32x4 qa = q[0], qb = q[1];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    u32x4 ta[8], tb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {  // eight loads in flight; rows past the end are clamped, then ignored
+      const u32 r = min(b0 + (u32)((k & 3) + 8 * (2 * g + (k >> 2))), t1 - 1);
+      ta[k] = tr[2 * (size_t)r];
+      tb[k] = tr[2 * (size_t)r + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32 r = b0 + (u32)((k & 3) + 8 * (2 * g + (k >> 2)));
+      const u32 dr = __popc(qa.x ^ ta[k].x) + __popc(qa.y ^ ta[k].y) + __popc(qa.z ^ ta[k].z) + __popc(qa.w ^ ta[k].w) +
+                     __popc(qb.x ^ tb[k].x) + __popc(qb.y ^ tb[k].y) + __popc(qb.z ^ tb[k].z) + __popc(qb.w ^ tb[k].w);
+      if (r < t1 && r != idx) s = min(s, dr);
+    }
+  }
+  return s;
+}
+
 // keypoints.h:295-296: int(best) < threshold && dist_2_best*best <= second, plus
 // "best_match == -1 can never be emitted" (distance 256).
 __device__ __forceinline__ bool accepted(uint2 v, const uint16_t* lut, int threshold, u32& idx) {
