@@ -579,7 +579,7 @@ def main():
             roffs2 = torch.empty(len(rp) + 1, dtype=torch.int64, device=dev)
             rout2 = torch.empty((len(rp) * n_rd, 2), dtype=torch.int32, device=dev)
             rl = {}
-            for name, variant in (("chosen", 0), ("key_form_forced", 0xD00000), ("popcount_scan", 0x2000000)):
+            for name, variant in (("chosen", 0), ("popcount_scan", 0x2000000)):
                 mr.set_variant(variant)
                 mr.set_profiling(True)
                 for _ in range(2):
@@ -594,9 +594,6 @@ def main():
                             "forward_gcomps": k0["comparisons"] / max(k0["scan_ms"], 1e-9) / 1e6,
                             "backward_scan_ms": k1["scan_ms"], "matches_per_pair": tot / len(rp)}
                 if name == "chosen":
-                    mode, share = mr.scan_tracking()
-                    rl[name]["tracking_form"] = "distances" if mode == 1 else "keys"
-                    rl[name]["share_of_steps_off_the_common_path"] = share
                     chk = rrng.choice(len(rp), size=24, replace=False)
                     oh = roffs2.cpu().numpy()
                     impl = _ob.ref() or _ob.port()

@@ -30,6 +30,14 @@
  * Threading: a vsm_ctx serialises its calls with an internal mutex; use one
  * context per thread for concurrency (the C++ shim keeps a thread_local one,
  * which makes it re-entrant for the tbb::parallel_for of src/sfm.cpp:1295).
+ *
+ * Stream ordering: all work of a context runs on its own non-blocking HIP stream
+ * (vsm_stream()), which has NO implicit ordering with the null stream, with another library's
+ * stream or with a collective's stream.  Device buffers handed to vsm_db_attach, vsm_nn2_device,
+ * vsm_match_pairs_device or vsm_match_pair_noalloc must be complete before the call: synchronise
+ * the producing stream (or the device) first, or make vsm_stream() wait on an event the
+ * producer recorded (hipStreamWaitEvent).  Likewise wait for vsm_stream() before another stream
+ * reads the outputs of the entry points that return before their work has run.
  */
 #ifndef VSMATCH_H
 #define VSMATCH_H
@@ -227,17 +235,9 @@ int vsm_last_scan_stats_kind(vsm_ctx* ctx, int kind, double* ms, uint64_t* launc
                              uint64_t* comparisons);
 /* Enable/disable the event timing above (off by default; costs two events per launch). */
 int vsm_set_profiling(vsm_ctx* ctx, int enabled);
-/* Kernel variant selector for experiments: 0 = default. See DESIGN.md. */
+/* Kernel variant selector for experiments and for the parity tests, which drive every kernel shape
+ * through it: 0 = default (what ships).  Bits are listed at choose_shape in csrc/vsmatch.hip. */
 int vsm_set_variant(vsm_ctx* ctx, int variant);
-/*
- * Which tracking form the matrix-core forward scan of the NEXT batched call on this context will
- * use -- 0 = float keys (fastest when almost no 32 x 32 block holds a distance below the accept
- * limit: synthetic iid descriptors), 1 = distances with index recovery (real ORB descriptors,
- * whose unrelated pairs are often closer than the limit) -- and the share of 32 x 32 steps of the
- * last batched call that left the common path (-1 before the first call).  The library chooses
- * by itself after every batched call; results are identical either way.
- */
-int vsm_scan_tracking(vsm_ctx* ctx, int* mode, double* slow_share);
 /*
  * Host-only helper (no GPU, no context; for tests): the distance L in [1, 256] at which the
  * matrix-core scan starts its best / second best for the accept test of keypoints.h:295-296

@@ -44,8 +44,7 @@ def test_null_context_is_rejected():
     n = C.c_size_t(0)
     assert L.vsm_match_pair(None, None, 0, None, 0, 70, 1.2, None, 0, C.byref(n)) == vsm.matcher.VSM_ERR_INVALID
     assert b"null context" in L.vsm_last_error()
-    mode, share = C.c_int(7), C.c_double(7.0)
-    assert L.vsm_scan_tracking(None, C.byref(mode), C.byref(share)) == vsm.matcher.VSM_ERR_INVALID
+    assert L.vsm_set_variant(None, 0) == vsm.matcher.VSM_ERR_INVALID
 
 
 def test_accept_limit_is_invisible_to_the_accept_test():

@@ -47,24 +47,29 @@ def test_pair_matches_recorded_reference(m, name):
     assert np.array_equal(got, binding.port().match(d1, d2, thr, ratio))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8, 0x20001, 0x20002, 0x20004, 0x20008, 0x0301, 0x20304, 0x4008,
-                                     0x40008, 0x60008, 0x40308, 0x80001, 0x80004, 0x80008, 0xC0008, 0x1000008, 0x1020008,
-                                     0x0308, 0x2000008, 0x2000308, 0x10000008, 0x20000008, 0x40000008, 0x12000008, 0x20000208, 0x4000008, 0x8000001, 0x8000000,
-                                     0xE00008, 0xD00008, 0xC00008, 0x10E00008, 0x20E00008, 0xE00308, 0xE00001, 0xD00001])
+# Experiment knob (choose_shape, csrc/vsmatch.hip): low byte 1 / 4 / 8 = latency shape (64-query
+# tiles, 4-wave workgroups) / fixed 256-query popcount tiles / adaptive tiles; bits 8-15 train
+# splits; bit 16 no backward pruning; bit 17 integer keys (popcount); bit 25 popcount everywhere,
+# 26 in the pruned backward pass, 27 in the latency shape; bits 28-30 adaptive full-tile size.
+POPCOUNT, INT_KEYS, NO_PRUNE, POP_BACK, POP_LAT = 0x2000000, 0x20000, 0x10000, 0x4000000, 0x8000000
+TILE256, TILE128, TILE64 = 0x40000000, 0x20000000, 0x10000000
+
+
+@pytest.mark.parametrize("variant", [1, 4, 8, 0x0301, 0x0308, 0x1708, 0x4008, TILE256 | 8, TILE128 | 8, TILE64 | 8, TILE128 | 0x0208,
+                                     POPCOUNT | 1, POPCOUNT | 4, POPCOUNT | 8, POPCOUNT | 0x0308, POPCOUNT | 0x0301,
+                                     POPCOUNT | INT_KEYS | 1, POPCOUNT | INT_KEYS | 4, POPCOUNT | INT_KEYS | 8,
+                                     POPCOUNT | TILE256 | 8, POPCOUNT | TILE128 | 8, POPCOUNT | TILE64 | 8,
+                                     POPCOUNT | INT_KEYS | TILE128 | 0x0308, POP_BACK | 8, POP_LAT | 1, POP_LAT, NO_PRUNE | 8])
 def test_pair_all_kernel_shapes(m, variant):
-    """Every instantiation (queries per lane 1/2/4/8 x float-key / integer-key
-    tracking [bit 17], with forced train splits [bits 8-15]; R = 8 runs the adaptive tile
-    decomposition unless bit 18 is set -- on the matrix cores (mfma_scan.h) unless bit 25 asks
-    for the popcount scan; bits 28-30 force the tile size; bits 19 / 24 select earlier popcount
-    forms: 512-query tiles without the skip test, one-wave / 4-wave workgroups; nibble 20-23 =
-    14 / 13 / 12 forces the distance form / the key form / distances in forward scans only) gives
-    the same list."""
+    """Every kernel instantiation of the library -- matrix-core scan at 256/128/64-query adaptive
+    tiles and in the 4-wave latency shape, with forced train splits; popcount scan in the same
+    shapes with float and integer keys -- gives the recorded reference lists."""
     m.set_variant(variant)
     try:
         for name in ("ex3_thr70_r1.2", "planted_300x777", "planted_1023x1025", "planted_4100x130",
                      "edge_all_identical", "edge_all_256_thr300_ratio1", "edge_tie_best"):
             d1, d2, thr, ratio = cases.build_case(name)
-            assert sha(m.match(d1, d2, thr, ratio)) == REF["cases"][name]["sha256"], (variant, name)
+            assert sha(m.match(d1, d2, thr, ratio)) == REF["cases"][name]["sha256"], (hex(variant), name)
     finally:
         m.set_variant(0)
 
@@ -76,7 +81,7 @@ def test_accept_limit_of_the_matrix_core_scan(m, thr, ratio):
     """The matrix-core scan starts (best, second) at the smallest distance the accept test
     cannot tell from anything larger (accept_limit, vsmatch.hip); whatever threshold and ratio
     that limit is derived from, the list is the oracle's."""
-    for variant in (0xD00008, 0x10D00008, 0xD00308, 0xE00008, 0x10E00008, 0xE00308):
+    for variant in (8, TILE64 | 8, 0x0308, 1, 0x0301):
         m.set_variant(variant)
         try:
             for (n1, n2, seed) in [(300, 777, 1), (1023, 1025, 2), (64, 33, 3), (5, 2000, 4)]:
@@ -98,11 +103,11 @@ def _real_like_database(n_img, n_desc, seed):
     return db, (np.arange(n_img + 1) * n_desc).astype(np.uint32)
 
 
-@pytest.mark.parametrize("variant", [0xE00008, 0x10E00008, 0x20E00008, 0xE00308, 0xD00008, 0xE00001, 0xD00001])
+@pytest.mark.parametrize("variant", [8, TILE64 | 8, TILE128 | 8, 0x0308, 1, 0x0501, POPCOUNT | 8])
 def test_real_descriptors_every_tail_length(m, variant):
-    """Real ORB descriptors (many near neighbours: the slow paths run in nearly every step) at
-    train sizes around the 32-row step of the matrix-core scan -- the partial last step is handled
-    apart from the pipelined loop -- under both tracking forms; also raw 2-NN."""
+    """Real ORB descriptors (many near neighbours, ties and second bests right next to the best)
+    at train sizes around the 32-row step of the matrix-core scan -- the partial last step is
+    handled apart from the pipelined loop; also raw 2-NN, whose second best is refined for every query."""
     real = np.concatenate(cases.ex3())
     noisy = real ^ cases.synth.flip_masks(len(real), 3, 77, levels=(5, 6))
     m.set_variant(variant)
@@ -117,43 +122,81 @@ def test_real_descriptors_every_tail_length(m, variant):
         m.set_variant(0)
 
 
-def test_tracking_form_follows_the_data_and_never_changes_the_lists():
-    """The matrix-core forward scan has two tracking forms (mfma_scan.h); the context picks one
-    after every batched call from the share of steps that left the common path.  Real-like
-    descriptors -> distances, iid random ones -> keys; the lists equal the oracle's under either
-    form, forced or chosen, pruned backward pass included."""
+def _neighbours_next_to_the_best(n, seed, gap):
+    """Queries whose two nearest train descriptors sit `gap` rows apart: the matrix-core scan
+    keeps one minimum per group of 16 rows (rows 4h + (k & 3) + 8 (k >> 2) of a 32-row step), so
+    a second best inside the best's group only comes out of refine_second.  Flip counts vary so
+    that the ratio test passes for some queries and fails for others."""
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 2 ** 63, size=(n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    per = 2 + gap
+    t = rng.integers(0, 2 ** 63, size=(n * per, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(n * per, 4), dtype=np.uint64)
+
+    def flipped(d, k):
+        out = d.copy()
+        for bit in rng.choice(256, size=k, replace=False):
+            out[bit // 64] ^= np.uint64(1) << np.uint64(bit % 64)
+        return out
+
+    for i in range(n):
+        k1 = int(rng.integers(0, 30))
+        k2 = k1 + int(rng.integers(0, 12))  # 0: a tie; small: the ratio test fails; large: it passes
+        a = i * per
+        b = a + gap
+        first, second = (a, b) if rng.integers(0, 2) else (b, a)
+        t[first] = flipped(q[i], k1)
+        t[second] = flipped(q[i], k2)
+    return q, t
+
+
+@pytest.mark.parametrize("gap", [1, 2, 3, 8, 9, 16, 24, 4, 5, 33])
+def test_second_best_next_to_the_best(m, gap):
+    """gap 1-3, 8, 9, 16, 24: both neighbours can share a group (same 4-row chunk, or chunks 8
+    rows apart); 4, 5: the other half of the step; 33: another step.  Single pair (merge_refine),
+    batch (nominate / count_list refinement, both directions), raw 2-NN (finalize), each against
+    the oracle, in every scan shape."""
+    q, t = _neighbours_next_to_the_best(150, 100 + gap, gap)
+    o = binding.port()
+    want, want_t = o.match(q, t, 70, 1.2), o.match(t, q, 70, 1.2)
+    assert 10 < len(want) < 140  # some pass the ratio test, some do not
+    off = np.array([0, len(q), len(q) + len(t)], np.uint32)
+    db = np.concatenate([q, t])
+    pairs = np.array([[0, 1], [1, 0]] * 1100, np.uint32)  # enough jobs for the adaptive regime
+    for variant in (0, 1, 8, TILE64 | 8, 0x0308, 0x0301, NO_PRUNE | 8, POPCOUNT | 8):
+        m.set_variant(variant)
+        try:
+            assert np.array_equal(m.match(q, t, 70, 1.2), want), (hex(variant), gap)
+            assert np.array_equal(m.match(t, q, 70, 1.2), want_t), (hex(variant), gap)
+            for g, w in zip(m.nn2(q, t), o.nn2(q, t)):
+                assert np.array_equal(g, w), (hex(variant), gap)
+            m.db_upload(db, off)
+            offs, lists = m.match_pairs(pairs, 70, 1.2)
+            for k in (0, 1, 2198, 2199):
+                assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want if k % 2 == 0 else want_t), (hex(variant), gap, k)
+            assert int(offs[-1]) == 1100 * (len(want) + len(want_t))
+        finally:
+            m.set_variant(0)
+
+
+def test_real_like_database_batched():
+    """A database with the distance statistics of real ORB descriptors (unrelated descriptors
+    126 +- 19 bits apart; duplicates, ties, crowded neighbourhoods): the batched matcher's lists
+    equal the oracle's in every form -- matrix cores, without pruning, popcount, mixed."""
     with vsm.Matcher(0) as mm:
-        assert mm.scan_tracking() == (1, -1.0)
         db, off = _real_like_database(64, 900, 5)  # 2016 pairs: enough waves for the batched (adaptive) scan
         pairs = cases.synth.all_pairs(64)
         mm.db_upload(db, off)
         want = [binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2) for i, j in pairs.tolist()]
         assert sum(len(w) for w in want) > 10000
-        for variant in (0, 0, 0xE00000, 0xD00000, 0xC00000, 0x2000000):
+        for variant in (0, NO_PRUNE, POPCOUNT, POP_BACK, TILE64, 0x0200, 1):
             mm.set_variant(variant)
             offs, out = mm.match_pairs(pairs, 70, 1.2)
             for k, w in enumerate(want):
                 assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], w), (hex(variant), k)
-            mode, share = mm.scan_tracking()
-            if variant != 0x2000000:
-                assert mode == 1 and share > 0.5, (hex(variant), mode, share)
-        mm.set_variant(0)
-        db, off = cases.synth.sfm_database(70, 1000, seed=12)
-        pairs = cases.synth.all_pairs(70)
-        mm.db_upload(db, off)
-        o1, l1 = mm.match_pairs(pairs, 70, 1.2)      # still the distance form
-        mode, share = mm.scan_tracking()
-        assert mode == 0 and 0 <= share < 0.05, (mode, share)
-        o2, l2 = mm.match_pairs(pairs, 70, 1.2)      # now keys
-        assert np.array_equal(o1, o2) and np.array_equal(l1, l2)
-        for k in range(0, len(pairs), 37):
-            i, j = pairs[k]
-            assert np.array_equal(l2[int(o2[k]):int(o2[k + 1])],
-                                  binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2))
 
 
 def test_nn2_vs_oracle(m):
-    for variant in (0, 0x20000, 8, 0x2000008, 0x10000008, 0xD00008, 0x10D00008, 0xE00001):
+    for variant in (0, 8, 1, TILE64 | 8, TILE128 | 8, POPCOUNT | 8, POPCOUNT | INT_KEYS, POP_LAT | 1):
         m.set_variant(variant)
         try:
             for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6),
@@ -216,7 +259,7 @@ def test_pruned_backward_pass_equals_full(m):
         m.set_variant(0)
         o1, l1 = m.match_pairs(pairs, 70, 1.2)
         ev_pruned = m.last_scan_stats()["comparisons"]
-        m.set_variant(0x10000)
+        m.set_variant(NO_PRUNE)
         try:
             o2, l2 = m.match_pairs(pairs, 70, 1.2)
             ev_full = m.last_scan_stats()["comparisons"]
@@ -301,8 +344,8 @@ def test_config3_shape_euroc_like_all_pairs(m):
 
 
 def test_nn2_large_sampled_against_oracle(m):
-    """One-direction scan at 200k x 200k (several float-key ranges, R = 8): invariants on
-    every query, exact values on a sample."""
+    """One-direction scan at 200k x 200k (several train splits): invariants on every query,
+    exact values on a sample."""
     n = 200_000
     q, t = cases.synth.planted_sets(n, seed=8)
     bi, bd, sd = m.nn2(q, t)
@@ -316,10 +359,10 @@ def test_nn2_large_sampled_against_oracle(m):
 
 
 def test_adaptive_tiles_on_ragged_database(m):
-    """scan_kernel_adaptive: image sizes on and around every tile boundary (multiples of 64 up to
+    """Adaptive tiles: image sizes on and around every tile boundary (multiples of 64 up to
     1025, so every 256/128/64 remainder combination occurs, forward and in the pruned backward
-    pass), all pairs as one batch large enough for the R = 8 regime, against the oracle; the
-    fixed-tile kernels (variant bit 18) must give the same lists."""
+    pass), all pairs as one batch large enough for the adaptive regime, against the oracle; every
+    tile size and scan form must give the same lists."""
     sizes = [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 319, 320, 321, 383, 384, 385, 447, 448,
              449, 511, 512, 513, 575, 576, 577, 640, 704, 768, 832, 896, 959, 960, 961, 1023, 1024, 1025]
     db, off = cases.synth.sfm_database(len(sizes), sizes, seed=77, share_frac=0.5, window=40)
@@ -327,9 +370,10 @@ def test_adaptive_tiles_on_ragged_database(m):
     pairs = np.concatenate([pairs, pairs[:, ::-1]])  # both orientations
     m.db_upload(db, off)
     offs, lists = m.match_pairs(pairs, 70, 1.2)
-    # fixed 512-query tiles; 512-query adaptive tiles, 1- and 4-wave; forced full-tile sizes 256 / 128 / 64,
-    # the last two also with integer keys
-    for variant in (0x40000, 0x80000, 0x1000000, 0x40000000, 0x20000000, 0x10000000, 0x20020000, 0x10020000):
+    # forced full-tile sizes 256 / 128 / 64 on the matrix cores and with the popcount scan (float and
+    # integer keys), no pruning, popcount backward pass only
+    for variant in (TILE256, TILE128, TILE64, POPCOUNT | TILE256, POPCOUNT | TILE128, POPCOUNT | INT_KEYS | TILE64,
+                    NO_PRUNE, POP_BACK):
         m.set_variant(variant)
         try:
             offs_v, lists_v = m.match_pairs(pairs, 70, 1.2)

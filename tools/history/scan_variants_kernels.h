@@ -10,13 +10,10 @@
 //   finalize_nn2     unpacks the scan result for the raw 2-NN entry point.
 //
 // This file: the popcount form of the scan, integer VALU work only (v_xor_b32 +
-// v_bcnt_u32_b32 with its free accumulate) -- the formulation BASELINE.json's north_star
-// describes, 0.92 of the integer-VALU roofline, kept as the reference point bench.py reports
-// (`popcount_path`) and reachable through vsm_set_variant -- and the consumer kernels.  The
-// shipped scan is the matrix-core form in mfma_scan.h (same jobs, same scratch layout, same
-// results, 5x faster: a Hamming distance is also a +-1 dot product).  The earlier popcount
-// variants (no filler, s_nop filler, float keys without the skip test, 512-query tiles,
-// LDS-staged train tiles) live in tools/history/scan_variants_kernels.h with their harness.
+// v_bcnt_u32_b32 with its free accumulate).  It serves short jobs (one stereo pair, split
+// scans) and train ranges of more than 32768 descriptors per split; large batches run the
+// matrix-core form in mfma_scan.h (same jobs, same scratch layout, same results), which turned
+// out 5x faster: a Hamming distance is also a +-1 dot product.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,41 +62,45 @@ __device__ __forceinline__ u32 med3_u32(u32 a, u32 b, u32 c) {
 // popcount(x) + acc in one instruction (the accumulate operand of v_bcnt is free).
 // Written as asm because the compiler otherwise re-associates the eight counts
 // into v_bcnt(x, 0) + v_add3_u32 trees, three instructions more per comparison.
-// A v_mov is glued behind each v_bcnt (tools/valu_rate2: on gfx950 a v_bcnt occupies the SIMD
-// for ~4.6 cycles but a following v_mov / s_nop / f32 add, mul or fma of the same wave issues in
-// its shadow, and the v_xor after that then runs at the 2.3-cycle rate instead of 4.6).
+//
+// FILL selects an issue-slot filler glued behind each v_bcnt (tools/valu_rate2:
+// on gfx950 a v_bcnt occupies the SIMD for ~4.4 cycles but a following s_nop /
+// v_mov of the same wave issues in its shadow, and the v_xor after that then
+// runs at the 2.3-cycle rate instead of 4.4):  0 none, 1 s_nop 0, 2 v_mov.
+template <int FILL>
 __device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
-  u32 r, junk;
-  asm("v_bcnt_u32_b32 %0, %2, %3\n\tv_mov_b32 %1, %2" : "=v"(r), "=&v"(junk) : "v"(x), "v"(acc));
+  u32 r;
+  if (FILL == 1 || FILL == 4) asm("v_bcnt_u32_b32 %0, %1, %2\n\ts_nop 0" : "=v"(r) : "v"(x), "v"(acc));
+  else if (FILL == 2 || FILL == 3) { u32 junk; asm("v_bcnt_u32_b32 %0, %2, %3\n\tv_mov_b32 %1, %2" : "=v"(r), "=&v"(junk) : "v"(x), "v"(acc)); }
+  else asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
   return r;
 }
+template <int FILL>
 __device__ __forceinline__ u32 bcnt0(u32 x) {
-  u32 r, junk;
-  asm("v_bcnt_u32_b32 %0, %2, 0\n\tv_mov_b32 %1, %2" : "=v"(r), "=&v"(junk) : "v"(x));
+  u32 r;
+  if (FILL == 1 || FILL == 4) asm("v_bcnt_u32_b32 %0, %1, 0\n\ts_nop 0" : "=v"(r) : "v"(x));
+  else if (FILL == 2 || FILL == 3) { u32 junk; asm("v_bcnt_u32_b32 %0, %2, 0\n\tv_mov_b32 %1, %2" : "=v"(r), "=&v"(junk) : "v"(x)); }
+  else asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
   return r;
 }
 
-// One train descriptor (wave-uniform, in SGPRs) against the R query descriptors each lane holds
-// in VGPRs.  Invariant best <= second, so the new second is the median of (best, key, second).
+// One train descriptor (wave-uniform, in SGPRs) against the R query descriptors
+// each lane holds in VGPRs: 8 xor + 8 bcnt + key + med3 + min per comparison.
+// Invariant best <= second, so the new second is the median of (best, key, second).
 //
-// FILL == 2: integer keys, 8 xor + 8 bcnt (each with its v_mov filler) + v_lshl_or + v_med3_u32 +
-// v_min_u32 per comparison.  Any train range.
-//
-// FILL == 8: float keys for train ranges of <= 32768 descriptors.  The popcount chain is seeded
-// with 0x4B000000, the bit pattern of 2^23, so its result read as f32 is exactly 2^23 + d.  Then
+// FILL == 5: float-key tracking for train sets of <= 32768 descriptors.  The
+// popcount chain is seeded with 0x4B000000, the bit pattern of 2^23, so its
+// result read as f32 is exactly 2^23 + d.  Then
 //     df  = chain - 2^23                       (v_add_f32, exact)
 //     key = df * 32768 + (2^23 + j)            (v_fma_f32, exact: < 2^24 for d <= 255)
-// is an f32 whose order is (distance, index) lexicographic.  Both instructions are of the class
-// that issues in the shadow of a v_bcnt, and they ride in the filler slots of the NEXT
-// comparison's chain (behind its first two v_bcnt; v_mov behind the other six), so the key costs
-// no issue slot.  v_med3_f32 / v_min_f32 run only if some lane's key is below its second best
-// (v_cmp_lt_f32 + s_cbranch: exact, they would return their old values otherwise).  Distance 256
-// gives key >= 2^24 = the start value: never recorded.  `Pend` carries the last chain of one call
-// (its popcount result and the bit pattern of 2^23 + j) into the next call; scan_tile flushes it
-// after the last train descriptor.
+// is an f32 whose order is (distance, index) lexicographic, and best/second are
+// kept with v_med3_f32 / v_min_f32.  The two f32 instructions are of the class
+// that issues in the shadow of a v_bcnt (tools/valu_rate2), so the v_add_f32
+// replaces the filler of the last v_bcnt and the integer v_lshl_or_b32
+// disappears.  Distance 256 gives key >= 2^24 = the start value: never recorded.
 constexpr u32 FKEY_MAGIC = 0x4B000000u;   // 2^23 as f32
 constexpr u32 FKEY_INIT = 0x4B800000u;    // 2^24 as f32 = distance 256, index 0
-constexpr u32 FKEY_MAX_SET = 32768;       // also the most rows per split of the matrix-core scan (1024 steps)
+constexpr u32 FKEY_MAX_SET = 32768;
 // f32 key -> packed integer key; `base` = first train index of the scanned range
 // (float keys index relative to it so that any range of <= 32768 descriptors works).
 __device__ __forceinline__ u32 fkey_to_key(u32 fbits, u32 base) {
@@ -107,6 +108,20 @@ __device__ __forceinline__ u32 fkey_to_key(u32 fbits, u32 base) {
   const u32 d = k >> 15;
   return d >= 256u ? KEY_INIT : ((d << IDX_BITS) | ((k & 32767u) + base));
 }
+
+// FILL == 7: float keys as in 5, with the key construction of a comparison riding in the filler
+// slots of the NEXT comparison's popcount chain: v_add_f32 and v_fma_f32 sit behind its first
+// two v_bcnt (where FILL 5 has a v_mov), v_med3_f32 + v_min_f32 follow (the min is the med3's
+// filler), v_mov behind the other six v_bcnt: 26 issued instructions per comparison instead of
+// 27.  Measured (tools/scan_variants, profiles/r01/scan_variants_piggyback.txt): R = 8 +1.6 %,
+// R = 4 +5 % over FILL 5.  v_min_f32 / v_max_f32 / v_med3_f32 do NOT work as fillers (moving
+// them into filler slots too, 24-25 instructions, is slower), only add/mul/fma f32 and v_mov do.
+// FILL == 8 (shipped with 256-query tiles): FILL 7 plus a wave-level test -- the v_med3_f32 /
+// v_min_f32 pair runs only if some lane's key is below its second best (v_cmp_lt_f32 +
+// s_cbranch).  At 4 queries per lane (61 VGPRs, 8 waves per SIMD to cover the branch) this is
+// +4 % over FILL 7 at 8 queries per lane; at 8 queries per lane it loses (128 VGPRs).
+// `Pend` carries the last chain of one call (its popcount result and the bit pattern of
+// 2^23 + j) into the next call; scan_tile flushes it after the last train descriptor.
 struct Pend {
   u32 d, jf;
 };
@@ -115,8 +130,7 @@ constexpr u32 PEND_INIT_D = FKEY_MAGIC + 256u;  // distance 256: a key >= FKEY_I
 template <int R, int FILL>
 __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 j, u32 (&best)[R],
                                        u32 (&second)[R], Pend& pend) {
-  static_assert(FILL == 2 || FILL == 8, "popcount scan: integer keys (2) or float keys with the skip test (8)");
-  if (FILL == 8) {
+  if (FILL == 7 || FILL == 8) {
     const u32 magic = FKEY_MAGIC;
     const float scale = 32768.0f;
     const u32 jf = FKEY_MAGIC + j;
@@ -130,28 +144,76 @@ __device__ __forceinline__ void update(const u32 (&q)[R][8], const u32x8 t, u32 
           : "=&v"(d), "=v"(df) : "v"(q[r][0] ^ t[0]), "v"(magic), "v"(dprev));
       asm("v_bcnt_u32_b32 %0, %2, %0\n\tv_fma_f32 %1, %3, %4, %5"
           : "+v"(d), "=v"(key) : "v"(q[r][1] ^ t[1]), "v"(df), "v"(scale), "s"(jfp));
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(__uint_as_float(key) < __uint_as_float(second[pr])) != 0, 0)) {
+      if (FILL == 8) {
+        // experiment: skip the tracking pair unless some lane's key beats its second best
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(__uint_as_float(key) < __uint_as_float(second[pr])) != 0, 0)) {
+          asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
+              : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
+          best[pr] = nb;
+          second[pr] = ns;
+        }
+      } else {
         asm("v_med3_f32 %0, %2, %3, %4\n\tv_min_f32 %1, %2, %3"
             : "=&v"(ns), "=&v"(nb) : "v"(best[pr]), "v"(key), "v"(second[pr]));
         best[pr] = nb;
         second[pr] = ns;
       }
 #pragma unroll
-      for (int w = 2; w < 8; w++) d = bcnt_acc(q[r][w] ^ t[w], d);
+      for (int w = 2; w < 8; w++) d = bcnt_acc<2>(q[r][w] ^ t[w], d);
       dprev = d;
     }
     pend.d = dprev;
     pend.jf = jf;
     return;
   }
+  if (FILL == 5) {
+    const u32 magic = FKEY_MAGIC;
+    const float scale = 32768.0f;
+    const u32 jf = FKEY_MAGIC + j;  // SALU: bit pattern of 2^23 + j
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      u32 d = bcnt_acc<2>(q[r][0] ^ t[0], magic);
+#pragma unroll
+      for (int w = 1; w < 7; w++) d = bcnt_acc<2>(q[r][w] ^ t[w], d);
+      u32 nb, ns, key, df;
+      asm("v_bcnt_u32_b32 %3, %4, %5\n\t"
+          "v_add_f32 %3, 0xcb000000, %3\n\t"
+          "v_fma_f32 %0, %3, %6, %7\n\t"
+          "v_med3_f32 %1, %8, %0, %9\n\t"
+          "v_min_f32 %2, %8, %0"
+          : "=&v"(key), "=&v"(ns), "=&v"(nb), "=&v"(df)
+          : "v"(q[r][7] ^ t[7]), "v"(d), "v"(scale), "s"(jf), "v"(best[r]), "v"(second[r]));
+      second[r] = ns;
+      best[r] = nb;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < R; r++) {
-    u32 d = bcnt0(q[r][0] ^ t[0]);
+    u32 d = bcnt0<FILL>(q[r][0] ^ t[0]);
 #pragma unroll
-    for (int w = 1; w < 8; w++) d = bcnt_acc(q[r][w] ^ t[w], d);
-    const u32 key = (d << IDX_BITS) | j;
-    second[r] = med3_u32(best[r], key, second[r]);
-    best[r] = min(best[r], key);
+    for (int w = 1; w < 8; w++) d = bcnt_acc<FILL>(q[r][w] ^ t[w], d);
+    u32 key;
+    if (FILL >= 3) {
+      // fillers behind the three tracking instructions too (3: v_mov, 4: s_nop)
+      u32 junk, nb, ns;
+      if (FILL == 3)
+        asm("v_lshl_or_b32 %0, %4, 23, %5\n\tv_mov_b32 %3, %4\n\t"
+            "v_med3_u32 %1, %6, %0, %7\n\tv_mov_b32 %3, %4\n\t"
+            "v_min_u32 %2, %6, %0\n\tv_mov_b32 %3, %4"
+            : "=&v"(key), "=&v"(ns), "=&v"(nb), "=&v"(junk) : "v"(d), "s"(j), "v"(best[r]), "v"(second[r]));
+      else
+        asm("v_lshl_or_b32 %0, %3, 23, %4\n\ts_nop 0\n\t"
+            "v_med3_u32 %1, %5, %0, %6\n\ts_nop 0\n\t"
+            "v_min_u32 %2, %5, %0\n\ts_nop 0"
+            : "=&v"(key), "=&v"(ns), "=&v"(nb) : "v"(d), "s"(j), "v"(best[r]), "v"(second[r]));
+      second[r] = ns;
+      best[r] = nb;
+    } else {
+      key = (d << IDX_BITS) | j;
+      second[r] = med3_u32(best[r], key, second[r]);
+      best[r] = min(best[r], key);
+    }
   }
 }
 
@@ -190,13 +252,13 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
   }
   u32 best[R], second[R];
 #pragma unroll
-  for (int r = 0; r < R; r++) best[r] = second[r] = (FILL == 8 ? FKEY_INIT : KEY_INIT);
+  for (int r = 0; r < R; r++) best[r] = second[r] = (FILL >= 5 ? FKEY_INIT : KEY_INIT);
   Pend pend = {PEND_INIT_D, FKEY_MAGIC};
 
   if (t1 > t0) {
     cdesc_t* tr = (cdesc_t*)(uintptr_t)tbase + job.t_off;
     const u32 last = t1 - 1;
-    const u32 jb = FILL == 8 ? t0 : 0u;  // float keys count from the start of the range
+    const u32 jb = FILL >= 5 ? t0 : 0u;  // float keys count from the start of the range
     u32 j = t0;
     // Software-pipelined: two groups of two descriptors in SGPRs; the loads of
     // one group are in flight while the other is consumed.  Indices past the
@@ -214,7 +276,7 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
     for (; j < t1; ++j) update<R, FILL>(q, tr[j], j - jb, best, second, pend);
   }
 
-  if (FILL == 8) {  // the last chain's tracking is still pending
+  if (FILL == 7 || FILL == 8) {  // the last chain's tracking is still pending
     const float key = fmaf(__uint_as_float(pend.d) - 8388608.0f, 32768.0f, __uint_as_float(pend.jf));
     const float b = __uint_as_float(best[R - 1]), sc = __uint_as_float(second[R - 1]);
     second[R - 1] = __float_as_uint(__builtin_amdgcn_fmed3f(b, key, sc));
@@ -224,7 +286,7 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
 #pragma unroll
   for (int r = 0; r < R; r++) {
     const u32 qi = q0 + r * 64 + lane;
-    if (FILL == 8) {
+    if (FILL >= 5) {
       best[r] = fkey_to_key(best[r], t0);
       second[r] = fkey_to_key(second[r], t0);
     }
@@ -232,7 +294,7 @@ __device__ __forceinline__ void scan_tile(const u32x4* __restrict__ qbase, const
   }
 }
 
-template <int R, int FILL>
+template <int R, int FILL = 0>
 __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qbase,
                                                    const u32x4* __restrict__ tbase,
                                                    const Job* __restrict__ jobs, u32 n_jobs,
@@ -249,16 +311,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const u32x4* __restrict__ qba
   scan_tile<R, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
 }
 
-// Ragged jobs (real images have 100..1400 corners, not a multiple of the tile): the job's queries
-// are cut into full tiles of 64 * RMAX and, for the remainder, one tile per set bit of
-// ceil(rest / 64) -- 128, 64 queries -- so that a wave never carries more than 63 idle query
-// slots.  adaptive_tiles(nq, rmax) on the host gives the number of tiles a job of nq queries has.
-__host__ __device__ inline u32 adaptive_tiles(u32 nq, u32 rmax) {  // rmax = 8, 4, 2 or 1
+// Ragged jobs (real images have 100..1400 corners, not a multiple of 512): the job's queries are
+// cut into tiles of 512 (R = 8) and, for the remainder, one tile per set bit of
+// ceil(rest / 64) -- 256, 128, 64 queries (R = 4, 2, 1) -- so that a wave never carries more than
+// 63 idle query slots.  Same grid as scan_kernel; the wave index within the job selects the
+// tile.  adaptive_tiles(nq, rmax) on the host gives the number of tiles a job of nq queries has.
+__host__ __device__ inline u32 adaptive_tiles(u32 nq, u32 rmax) {  // rmax = 8 or 4 (a power of two)
   const u32 n64 = (nq + 63) >> 6, rem = n64 & (rmax - 1);
   return n64 / rmax + ((rem >> 2) & 1) + ((rem >> 1) & 1) + (rem & 1);
 }
-// One-wave workgroups (the tiles of a ragged job run 1-4 x as long as each other, and a 4-wave
-// workgroup can only be placed when a slot is free on every SIMD of a CU at once).  Two block orders:
+// WAVES == 1 (the shipped form): one-wave workgroups.  Two block orders:
 //  * grouped (tiles_per_job > 0; used when every job has the same number of tiles):
 //    blockIdx.x = (group of 8 jobs, tile, job in group).  Workgroups are dealt round-robin to
 //    the 8 XCDs, so all tiles of a job land on the same XCD within 8 * tiles consecutive
@@ -267,27 +329,29 @@ __host__ __device__ inline u32 adaptive_tiles(u32 nq, u32 rmax) {  // rmax = 8, 
 //  * job-minor (tiles_per_job == 0; ragged jobs): blockIdx.x = tile * n_jobs + job.  The idle
 //    workgroups of jobs with fewer tiles then all sit at the end of the grid; interleaved with
 //    the live ones (grouped order) they cost a ragged batch 2.5x (measured, tools/ragged_probe).
-// RMAX: queries per lane of the full tiles (4 -> 256-query tiles, 2 -> 128, 1 -> 64).
-template <int FILL, int RMAX>
-__global__ __launch_bounds__(64) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
-                                                           const u32x4* __restrict__ tbase,
-                                                           const Job* __restrict__ jobs, u32 n_jobs,
-                                                           u32 splits, u32 split_stride,
-                                                           uint2* __restrict__ scratch,
-                                                           const u32* __restrict__ qlist,
-                                                           u32 tiles_per_job) {
-  static_assert(RMAX == 4 || RMAX == 2 || RMAX == 1, "256-, 128- or 64-query full tiles");
+// WAVES == 4: 4-wave workgroups in job-minor order.
+// RMAX: queries per lane of the full tiles (8 -> 512-query tiles, 4 -> 256-query tiles).
+template <int FILL, int WAVES = 4, int RMAX = 8>
+__global__ __launch_bounds__(64 * WAVES) void scan_kernel_adaptive(const u32x4* __restrict__ qbase,
+                                                                   const u32x4* __restrict__ tbase,
+                                                                   const Job* __restrict__ jobs, u32 n_jobs,
+                                                                   u32 splits, u32 split_stride,
+                                                                   uint2* __restrict__ scratch,
+                                                                   const u32* __restrict__ qlist,
+                                                                   u32 tiles_per_job) {
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   u32 job_id, t;
-  if (tiles_per_job) {
+  if (WAVES == 1 && tiles_per_job) {
     const u32 per_group = 8 * tiles_per_job;
     const u32 group = blockIdx.x / per_group, r = blockIdx.x - group * per_group;
     t = r >> 3;
     job_id = group * 8 + (r & 7);
     if (job_id >= n_jobs) return;
   } else {
-    t = blockIdx.x / n_jobs;
-    job_id = blockIdx.x - t * n_jobs;
+    const u32 wg_of_job = blockIdx.x / n_jobs;
+    job_id = blockIdx.x - wg_of_job * n_jobs;
+    t = wg_of_job * WAVES + wave;
   }
   const Job job = jobs[job_id];
   const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
@@ -295,9 +359,17 @@ __global__ __launch_bounds__(64) void scan_kernel_adaptive(const u32x4* __restri
     scan_tile<RMAX, FILL>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist);
     return;
   }
-  // remainder tiles in the order 128, 64 (those whose bit is set in rem)
+  // remainder tiles in the order 256, 128, 64 (those whose bit is set in rem)
   u32 k = t - full, q0 = full * 64 * RMAX;
-  if (RMAX > 2 && (rem & 2)) {
+  if (RMAX > 4 && (rem & 4)) {
+    if (k == 0) {
+      scan_tile<4, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
+      return;
+    }
+    k--;
+    q0 += 256;
+  }
+  if (rem & 2) {
     if (k == 0) {
       scan_tile<2, FILL>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist);
       return;
@@ -401,32 +473,6 @@ __device__ __forceinline__ bool cross_check(const uint2* __restrict__ scratch, c
 __device__ __forceinline__ void load_lut(uint16_t* lut, const AcceptParams& prm) {
   for (u32 k = threadIdx.x; k < 257; k += blockDim.x) lut[k] = prm.min_second[k];
   __syncthreads();
-}
-
-// Unpruned paths (one stereo pair; batches whose scans are split or whose images exceed the
-// nominate bitmap): folds the partial results of the train splits into split 0 like
-// merge_splits_kernel and, for results of the matrix-core scan that pass the accept test
-// (`refine` != 0), makes the second best exact (refine_second) -- in place, so the consumer
-// kernels after it read finished results with splits = 1.  One thread per scratch entry of the
-// chunk: entry e = pair e / (2 stride), direction (e / stride) & 1, query e % stride.
-__global__ __launch_bounds__(256) void merge_refine_kernel(const Job* __restrict__ jobs, u32 n_pairs, u32 stride,
-                                                           uint2* __restrict__ scratch, u32 splits, u32 split_stride,
-                                                           const u32x4* __restrict__ desc, AcceptParams prm, u32 refine) {
-  __shared__ uint16_t lut[260];
-  load_lut(lut, prm);
-  const u32 e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n_pairs * 2 * stride) return;
-  const u32 p = e / (2 * stride), rem = e - p * 2 * stride, dir = rem >= stride ? 1u : 0u, q = rem - dir * stride;
-  const Job job = jobs[dir ? n_pairs + p : p];
-  if (q >= job.nq) return;
-  uint2 v = load_merged(scratch, 0, e, splits, split_stride);
-  u32 idx;
-  if (refine && accepted(v, lut, prm.threshold, idx)) {
-    const u32 col = q;  // unpruned jobs have no query list
-    const u32 per = (job.nt + splits - 1) / splits;
-    v.y = refine_second(desc + 2 * (size_t)(job.q_off + col), desc + 2 * (size_t)job.t_off, job.nt, per, v) << IDX_BITS;
-  }
-  scratch[e] = v;
 }
 
 // counts[p] = number of matches of pair p.  One 256-thread workgroup per pair.
@@ -570,16 +616,6 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ 
   }
 }
 
-// One or two jobs handed over as kernel arguments (entry points that return before their work
-// has run must not stage them in host memory they reuse; entry points that may not allocate have
-// no other way).
-__global__ void set_jobs_kernel(Job* __restrict__ dst, Job a, Job b, u32 n) {
-  if (threadIdx.x == 0) {
-    dst[0] = a;
-    if (n > 1) dst[1] = b;
-  }
-}
-
 // jobs[p], jobs[n_pairs + p] for pair p = (pairs[p].x, pairs[p].y) of the database.
 // A pair naming an image >= n_img raises *bad and becomes an empty job pair.
 __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
@@ -607,26 +643,23 @@ __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
 
 // Pruned backward pass.  The cross-check (keypoints.h:354-360) only ever looks at
 // backward results of columns j = best1[i] of forward-ACCEPTED rows i, so only
-// those columns need a backward scan.  Per pair (one 256-thread workgroup):
-//  1. the forward-accepted rows i, ascending, go to flist[p*stride ...) -- from the accept bits the
-//     matrix-core forward scan left (mfma_scan.h store_accept_mask: 4 bytes per 32 rows instead
-//     of every 8-byte result) or, after a popcount scan, from the results themselves;
-//  2. after a matrix-core scan (`refine`) each listed row's second best is made exact
-//     (refine_second) and the rows that no longer pass are dropped from the list;
-//  3. the columns best1[i] of the listed rows are marked in an LDS bitmap, compacted ascending
-//     into qlist[p*stride ...) and the backward job is rewritten to scan just that list.
-// jobs[p].pad1 = number of listed rows: count_list_kernel / fill_list_kernel then read those few
-// rows instead of every row's result.  Exact: every backward result the consumer kernels read is
-// computed.  Needs stride <= NOMINATE_MAX_STRIDE (LDS bitmap) and splits == 1.
+// those columns need a backward scan.  Per pair (one 256-thread workgroup): mark
+// the nominated columns in an LDS bitmap, compact them ascending into
+// qlist[p*stride ...] and rewrite the backward job to scan just that list.
+// Exact: every backward result the consumer kernels read is computed.
+// Needs stride <= NOMINATE_MAX_STRIDE (LDS bitmap) and splits == 1.
 constexpr u32 NOMINATE_MAX_STRIDE = 65536;
+// It also writes the forward-accepted rows i, ascending, to flist[p*stride ...) and their number
+// to jobs[p].pad1: count_list_kernel / fill_list_kernel then read those few rows instead of
+// every row's result (three kernels each read all 8 B x N results of every pair: 130 us each per
+// 32768 pairs of 2000 descriptors, HBM-bound).
 __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
-                                                       uint2* __restrict__ scratch,
+                                                       const uint2* __restrict__ scratch,
                                                        AcceptParams prm, u32 stride,
                                                        u32* __restrict__ qlist,
                                                        u32* __restrict__ flist,
                                                        u64* __restrict__ comps,
-                                                       const u32* __restrict__ accmask,
-                                                       const u32x4* __restrict__ desc, u32 refine) {
+                                                       const u32* __restrict__ accmask) {
   __shared__ uint16_t lut[260];
   __shared__ u32 bitmap[NOMINATE_MAX_STRIDE / 32];
   __shared__ u32 wave_cnt[4];
@@ -638,86 +671,76 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   for (u32 w = threadIdx.x; w < words; w += 256) bitmap[w] = 0;
   __syncthreads();
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u32* list = flist + (size_t)p * stride;
-  // position of this thread's `cnt` items among the workgroup's, after `acc` earlier ones; returns
-  // the new total (two barriers)
-  auto place = [&](u32 cnt, u32 acc, u32& pos) {
-    u32 inc = cnt;
-    for (int o = 1; o < 64; o <<= 1) {
-      const u32 up = __shfl_up(inc, o);
-      if ((int)lane >= o) inc += up;
-    }
-    if (lane == 63) wave_cnt[wave] = inc;
-    __syncthreads();
-    u32 before = acc, all = 0;
-    for (u32 k = 0; k < 4; k++) {
-      if (k < wave) before += wave_cnt[k];
-      all += wave_cnt[k];
-    }
-    pos = before + inc - cnt;
-    __syncthreads();
-    return acc + all;
-  };
   u32 acc = 0;
   if (accmask) {
-    // a thread takes a 32-row word of accept bits
+    // the matrix-core forward scan left one accept bit per row (mfma_scan.h store_accept_mask):
+    // a thread takes a 32-row word, an exclusive prefix over the words gives its list position
     const u32 nw = (f.nq + 31) / 32;
     const u32* mw = accmask + (f.out_off >> 6);
     for (u32 base = 0; base < nw; base += 256) {
       const u32 w = base + threadIdx.x;
       u32 bits = w < nw ? mw[w] : 0u;
-      u32 pos;
-      acc = place((u32)__popc(bits), acc, pos);
+      const u32 cnt = (u32)__popc(bits);
+      u32 inc = cnt;
+      for (int o = 1; o < 64; o <<= 1) {
+        const u32 up = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += up;
+      }
+      if (lane == 63) wave_cnt[wave] = inc;
+      __syncthreads();
+      u32 before = acc, all = 0;
+      for (u32 k = 0; k < 4; k++) {
+        if (k < wave) before += wave_cnt[k];
+        all += wave_cnt[k];
+      }
+      u32 pos = before + inc - cnt;
       while (bits) {
-        list[pos++] = w * 32 + (u32)__builtin_ctz(bits);
+        const u32 i = w * 32 + (u32)__builtin_ctz(bits);
         bits &= bits - 1;
+        flist[(size_t)p * stride + pos++] = i;
+        const u32 j = scratch[f.out_off + i].x & IDX_MASK;
+        atomicOr(&bitmap[j >> 5], 1u << (j & 31));
       }
+      acc += all;
+      __syncthreads();
     }
-  } else {
-    for (u32 base = 0; base < f.nq; base += 256) {
-      const u32 i = base + threadIdx.x;
-      u32 j = 0, pos;
-      const bool hit = i < f.nq && accepted(scratch[f.out_off + i], lut, prm.threshold, j);
-      acc = place(hit ? 1u : 0u, acc, pos);
-      if (hit) list[pos] = i;
+  } else
+  for (u32 base = 0; base < f.nq; base += 256) {
+    const u32 i = base + threadIdx.x;
+    u32 j = 0;
+    const bool hit = i < f.nq && accepted(scratch[f.out_off + i], lut, prm.threshold, j);
+    if (hit) atomicOr(&bitmap[j >> 5], 1u << (j & 31));
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = acc, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
     }
-  }
-  __syncthreads();  // the list is read back below by other threads
-  // refine the listed rows, drop those that fail now (in place: a chunk writes at or below where
-  // it read, after every thread has read), mark the columns of the others
-  u32 kept = 0;
-  for (u32 base = 0; base < acc; base += 256) {
-    const u32 k = base + threadIdx.x;
-    u32 i = 0, j = 0;
-    bool keep = false;
-    if (k < acc) {
-      i = list[k];
-      uint2 v = scratch[f.out_off + i];
-      j = v.x & IDX_MASK;
-      keep = true;
-      if (refine) {
-        const u32 s = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, v);
-        keep = s >= (u32)lut[v.x >> IDX_BITS];
-      }
-    }
-    u32 pos;
-    kept = place(keep ? 1u : 0u, kept, pos);  // its barriers order this chunk's reads before the writes
-    if (keep) {
-      list[pos] = i;
-      atomicOr(&bitmap[j >> 5], 1u << (j & 31));
-    }
+    if (hit) flist[(size_t)p * stride + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    acc += all;
+    __syncthreads();
   }
   __syncthreads();
   u32 done = 0;
   for (u32 base = 0; base < n2; base += 256) {
     const u32 j = base + threadIdx.x;
     const bool hit = j < n2 && ((bitmap[j >> 5] >> (j & 31)) & 1u);
-    u32 pos;
-    done = place(hit ? 1u : 0u, done, pos);
-    if (hit) qlist[(size_t)p * stride + pos] = j;
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = done, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
+    }
+    if (hit) qlist[(size_t)p * stride + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = j;
+    done += all;
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
-    f.pad1 = kept;
+    f.pad1 = acc;
     jobs[p] = f;
     b.nq = done;
     b.qlist_off = p * stride;
@@ -737,10 +760,9 @@ __device__ __forceinline__ bool cross_check_listed(const uint2* __restrict__ scr
 
 // count_kernel / fill_kernel over the forward-accepted rows only (pruned path, unsplit scans).
 __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__ jobs,
-                                                         uint2* __restrict__ scratch,
+                                                         const uint2* __restrict__ scratch,
                                                          const u32* __restrict__ flist, u32 stride,
-                                                         AcceptParams prm, u32* __restrict__ counts,
-                                                         const u32x4* __restrict__ desc, u32 refine) {
+                                                         AcceptParams prm, u32* __restrict__ counts) {
   __shared__ uint16_t lut[260];
   __shared__ u32 total;
   if (threadIdx.x == 0) total = 0;
@@ -750,17 +772,7 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
   u32 mine = 0;
   for (u32 k = threadIdx.x; k < f.pad1; k += blockDim.x) {
     u32 j;
-    bool hit = cross_check_listed(scratch, f, b, list[k], lut, prm.threshold, j);
-    if (hit && refine) {
-      // backward result of the matrix-core scan: exact second best before it counts.  Written
-      // back, so that fill_list_kernel sees the finished result; column j has this one writer
-      // (only the row it points back at gets here).
-      const uint2 v = scratch[b.out_off + j];
-      const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, v);
-      if (s2 != min(v.y >> IDX_BITS, 256u)) scratch[b.out_off + j].y = s2 << IDX_BITS;
-      hit = s2 >= (u32)lut[v.x >> IDX_BITS];
-    }
-    mine += hit ? 1u : 0u;
+    mine += cross_check_listed(scratch, f, b, list[k], lut, prm.threshold, j) ? 1u : 0u;
   }
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
@@ -808,22 +820,17 @@ __global__ __launch_bounds__(256) void fill_list_kernel(const Job* __restrict__ 
 }
 
 // Unpacks scan results (keypoints.h:259-262 conventions: idx -1 / 256 / 256
-// when nothing closer than 256 exists); after a matrix-core scan (`refine`) the second best of
-// every query is made exact first.
+// when nothing closer than 256 exists).
 __global__ void finalize_nn2_kernel(const uint2* __restrict__ scratch, u32 nq, u32 splits,
                                     u32 split_stride, int* __restrict__ best_idx,
-                                    int* __restrict__ best_dist, int* __restrict__ second_dist,
-                                    const u32x4* __restrict__ query, const u32x4* __restrict__ train, u32 nt,
-                                    u32 refine) {
+                                    int* __restrict__ best_dist, int* __restrict__ second_dist) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   const uint2 v = load_merged(scratch, 0, i, splits, split_stride);
   const u32 d = v.x >> IDX_BITS;
-  u32 s = min(v.y >> IDX_BITS, 256u);
-  if (refine) s = refine_second(query + 2 * (size_t)i, train, nt, (nt + splits - 1) / splits, v);
   best_idx[i] = d < 256u ? (int)(v.x & IDX_MASK) : -1;
   best_dist[i] = (int)min(d, 256u);
-  second_dist[i] = (int)s;
+  second_dist[i] = (int)min(v.y >> IDX_BITS, 256u);
 }
 
 }  // namespace vsm

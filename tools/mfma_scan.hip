@@ -10,7 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#ifdef VSM_PRODUCT  // -DVSM_PRODUCT: the shipped kernel only (csrc/mfma_scan.h), for tuning it
 #include "mfma_scan.h"
+#else
+#include "history/mfma_scan_forms.h"
+#endif
 using namespace vsm;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
@@ -113,7 +117,11 @@ int main(int argc, char** argv) {
     CK(hipMemset(scr_ref, 0xff, n_scr * sizeof(uint2)));
     const u32 tiles = adaptive_tiles(N, 4), groups = (n_jobs + 7) / 8;
     CK(hipEventRecord(e0));
+#ifdef VSM_PRODUCT
+    scan_kernel_adaptive<8, 4><<<dim3(groups * 8 * tiles), dim3(64)>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr_ref, nullptr, tiles);
+#else
     scan_kernel_adaptive<8, 1, 4><<<dim3(groups * 8 * tiles), dim3(64)>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr_ref, nullptr, tiles);
+#endif
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipGetLastError());
@@ -125,8 +133,12 @@ int main(int argc, char** argv) {
   printf("%-28s %8.3f ms %9.1f Gcomp/s\n", "popcount adaptive<8,1,4>", t_ref, comps / (t_ref * 1e-3) / 1e9);
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
+#ifdef VSM_PRODUCT
+  const V vs[] = {{"shipped NB8", 24, 8}, {"shipped NB4", 24, 4}, {"shipped NB2", 24, 2}};
+#else
   const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2},
                   {"mfma group NB8", 24, 8}, {"mfma group NB4", 24, 4}, {"mfma group NB2", 24, 2}};
+#endif
   for (const V& v : vs) {
     float tm = 1e30f;
     const u32 tiles = adaptive_tiles(N, v.nb / 2), groups = (n_jobs + 7) / 8;
@@ -135,6 +147,11 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0));
       const dim3 g(groups * 8 * tiles), blk(64);
 #define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
+#ifdef VSM_PRODUCT
+      if (v.nb == 8) mfma_scan_kernel<8, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
+      else if (v.nb == 4) mfma_scan_kernel<4, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
+      else mfma_scan_kernel<2, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
+#else
       if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.fmt == 24 && v.nb == 8) mfma_scan_kernel<4, 8, 1, 2><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
@@ -143,6 +160,7 @@ int main(int argc, char** argv) {
       else if (v.nb == 8) mfma_scan_kernel<4, 8, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.nb == 4) mfma_scan_kernel<4, 4, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else mfma_scan_kernel<4, 2, 1, 1><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
+#endif
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       CK(hipGetLastError());

@@ -36,9 +36,8 @@ cap = len(pairs) * n_desc
 d_out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
 res = {"images": n_img, "desc_per_image": n_desc, "pairs": int(len(pairs))}
 lists = {}
-for name, variant in (("matrix_core_auto", 0), ("popcount", 0x2000000), ("matrix_core_distances", 0xE00000), ("matrix_core_keys", 0xD00000),
-                      ("matrix_core_distances_forward_only", 0xC00000), ("distances_128_query_tiles", 0x20E00000), ("distances_64_query_tiles", 0x10E00000),
-                      ("matrix_core_auto_again", 0)):
+for name, variant in (("matrix_core", 0), ("popcount", 0x2000000), ("matrix_core_128_query_tiles", 0x20000000),
+                      ("matrix_core_64_query_tiles", 0x10000000), ("matrix_core_unpruned", 0x10000), ("matrix_core_again", 0)):
     m.set_variant(variant)
     m.match_pairs_device(d_pairs.data_ptr(), len(pairs), 70, 1.2, d_offs.data_ptr(), d_out.data_ptr(), cap)
     m.set_profiling(True)
@@ -53,8 +52,7 @@ for name, variant in (("matrix_core_auto", 0), ("popcount", 0x2000000), ("matrix
     lists[name] = (d_offs.cpu().numpy().copy(), d_out[:total].cpu().numpy().copy())
     res[name] = {"pairs_per_s": len(pairs) / dt, "total_ms": dt * 1e3, "matches_per_pair": total / len(pairs),
                  "forward_ms": f["scan_ms"], "forward_gcomps": f["comparisons"] / (f["scan_ms"] * 1e-3) / 1e9,
-                 "backward_ms": b["scan_ms"], "backward_gcomps": b["comparisons"] / max(b["scan_ms"], 1e-9) / 1e6,
-                 "tracking_mode_after, slow_share": m.scan_tracking()}
+                 "backward_ms": b["scan_ms"], "backward_gcomps": b["comparisons"] / max(b["scan_ms"], 1e-9) / 1e6}
 res["lists_identical"] = all(bool(np.array_equal(lists["popcount"][0], v[0]) and np.array_equal(lists["popcount"][1], v[1]))
                              for v in lists.values())
 print(json.dumps(res))

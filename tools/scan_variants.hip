@@ -2,7 +2,7 @@
 // MI355X: same random job set, every variant timed interleaved in one process
 // (cdna_hip_programming.md rule 24), checksums compared.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ivisual-slam_amd/csrc tools/scan_variants.hip -o tools/scan_variants
-#include "vsmatch_kernels.h"
+#include "history/scan_variants_kernels.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

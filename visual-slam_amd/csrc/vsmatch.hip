@@ -140,11 +140,6 @@ struct vsm_ctx {
   u64 scan_launches[2] = {0, 0}, scan_comps[2] = {0, 0};
   std::vector<int> ev_kind;
   int variant = 0;
-  // Tracking form of the matrix-core forward scan: 1 = distances (robust: real descriptors,
-  // many near neighbours), 0 = float keys (fastest when almost no step leaves the common path).
-  // Chosen after every batched call from the share of steps that did (mfma_scan.h count_steps).
-  int scan_track = 1;
-  double last_slow_share = -1.0;
 };
 
 namespace {
@@ -240,18 +235,18 @@ int stats_collect(vsm_ctx* c) {
 }
 
 struct ScanShape {
-  int R;
+  bool adaptive;  // one-wave workgroups, full tiles of 64 * rmax queries + 128/64-query remainder tiles
+  int rmax;       // adaptive: queries per lane-pair of the full tiles in units of 64 (4, 2 or 1)
+  int R;          // fixed tiles (not adaptive): 64 * R queries per wave, 4-wave workgroups (1, or 4 through the knob)
   u32 wgs_per_job, splits;
-  bool fkey;      // float-key tracking (scan range per split <= FKEY_MAX_SET)
-  bool adaptive;  // scan_kernel_adaptive: 512-query tiles + 256/128/64 remainder tiles (R == 8 only)
   u32 tiles;      // most tiles a job has (adaptive: grid of one-wave workgroups = n_jobs x tiles)
   bool uniform;   // every job has exactly `tiles` tiles (grouped block order, see the kernel)
-  int rmax;       // adaptive: queries per lane of the full tiles (4 shipped, 8 with knob bits 19/24)
-  bool mfma;      // matrix-core scan (mfma_scan.h) instead of the popcount scan: adaptive + float keys
+  bool fkey;      // a split scans <= FKEY_MAX_SET rows: float keys (popcount) / 10-bit step tags (matrix cores)
+  bool mfma;      // matrix-core scan (mfma_scan.h); else the popcount scan (experiment knob only)
 };
 
-// Most tiles scan_kernel_adaptive can need for a job of at most max_nq queries (the tile
-// count is not monotone in nq: 448 queries are 3 tiles, 512 are 1).
+// Most tiles the adaptive kernels can need for a job of at most max_nq queries (the tile
+// count is not monotone in nq: 192 queries are 2 tiles at rmax = 4, 256 are 1).
 u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
   const u32 n64 = (max_nq + 63) >> 6;
   u32 best = 0;
@@ -259,47 +254,54 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
   return best;
 }
 
-// Queries per wave (64*R), tile form and train splits.  Large batches: the adaptive kernel
-// (256-query tiles or smaller, one-wave workgroups), no split.
-// Small problems (one stereo pair, odometry.cpp:814) are latency bound: one
-// query per lane and the train range split over grid.y so that all 256 CUs work.
+// Experiment knob (vsm_set_variant), kept for A/B runs and for the parity tests, which drive every
+// kernel shape through it:
+//   low byte    1 / 4 / 8: latency shape (64-query tiles, 4-wave workgroups) / fixed 256-query
+//               popcount tiles / adaptive tiles, whatever the job count says
+//   bits 8-15   number of train splits
+//   bit 16      no pruning of the backward pass
+//   bit 17      popcount scan with integer keys (FILL 2) instead of float keys (FILL 8)
+//   bit 25      popcount scan everywhere (the formulation of BASELINE.json's north_star)
+//   bit 26      popcount scan in the pruned backward pass only
+//   bit 27      popcount scan for the latency shape only
+//   bits 28-30  adaptive full-tile size: 4 / 2 / 1 = 256 / 128 / 64 queries
+constexpr int KNOB_NO_PRUNE = 0x10000, KNOB_INT_KEYS = 0x20000, KNOB_POPCOUNT = 0x2000000,
+              KNOB_POPCOUNT_BACKWARD = 0x4000000, KNOB_POPCOUNT_LATENCY = 0x8000000;
+
+// Tile form and train splits.  Large batches: adaptive tiles (256 queries or fewer), one-wave
+// workgroups, no split.  Small problems (one stereo pair, odometry.cpp:814) are latency bound:
+// 64-query tiles and the train range split over grid.y so that all 256 CUs work.
 ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u32* exact_max_tiles = nullptr,
                        const bool* uniform_tiles = nullptr, const double* avg_tiles = nullptr,
-                       u64 jobs_per_launch = 0, bool slow_steps = false) {
+                       u64 jobs_per_launch = 0) {
   ScanShape s;
-  // experiment knob (vsm_set_variant): low byte = R override, next byte = splits
-  // override, bit 17 = integer-key tracking everywhere
   const int vr = variant & 0xff, vs = (variant >> 8) & 0xff;
-  // 8 queries per lane when that still leaves enough waves to fill the chip (counting the
-  // long-scan splits that will be applied below), else 4, else 1 (latency regime).
+  // adaptive tiles when 256-query tiles still leave enough waves to fill the chip (counting the
+  // long-scan splits that will be applied below), else the latency shape
   const u64 long_splits = std::max(1u, max_nt / 4096);
-  const u64 waves_r8 = n_jobs * ((max_nq + 511) / 512) * long_splits;
   const u64 waves_r4 = n_jobs * ((max_nq + 255) / 256) * long_splits;
-  s.R = waves_r8 >= TARGET_WAVES ? 8 : waves_r4 >= TARGET_WAVES ? 4 : 1;
-  if (vr == 1 || vr == 2 || vr == 4 || vr == 8) s.R = vr;
-  const u32 tq = 64 * s.R;
-  // bit 18 of the experiment knob: fixed 512-query tiles instead of the adaptive decomposition
-  s.adaptive = s.R == 8 && !(variant & 0x40000);
-  // bits 19 / 24: the earlier forms (512-query tiles without the skip test; 4-wave workgroups)
-  s.rmax = (variant & (0x80000 | 0x1000000)) ? 8 : 4;
-  if (s.adaptive && s.rmax == 4) {
+  s.adaptive = waves_r4 >= TARGET_WAVES;
+  s.R = 1;
+  if (vr == 1) s.adaptive = false;
+  if (vr == 8) s.adaptive = true;
+  if (vr == 4) { s.adaptive = false; s.R = 4; }
+  s.rmax = 4;
+  if (s.adaptive) {
     // Shorter waves for smaller batches: keep >= ~16 rounds of the 8192 resident waves so the
     // tail of the launch stays small (tools/ragged_probe.py: at euroc_V1's image sizes 64-query
-    // tiles beat 256-query ones by 10 %); low nibble of byte 3 of the knob forces rmax.
+    // tiles beat 256-query ones by 10 %).
     const u64 ls = std::max<u64>(1, (max_nt + FKEY_MAX_SET - 1) / FKEY_MAX_SET);
     auto waves_at = [&](int rmax) {
-      const int ri = rmax == 8 ? 0 : rmax == 4 ? 1 : rmax == 2 ? 2 : 3;
+      const int ri = rmax == 4 ? 1 : rmax == 2 ? 2 : 3;
       const double per_job = avg_tiles ? avg_tiles[ri] : (double)adaptive_tiles(max_nq, (u32)rmax);
       return (double)(jobs_per_launch ? jobs_per_launch : n_jobs) * per_job * (double)ls;
     };
     while (s.rmax > 1 && waves_at(s.rmax) < 131072.0) s.rmax /= 2;
-    // Most steps leave the common path (real descriptors, distance form): the VALU-bound slow
-    // step likes three waves per SIMD, which the 128-query tile (142 VGPRs) allows: 8.4 -> 8.8 T.
-    if (slow_steps && s.rmax > 2) s.rmax = 2;
     const int force = (variant >> 28) & 0x7;
     if (force == 1 || force == 2 || force == 4) s.rmax = force;
   }
-  const int ri = s.rmax == 8 ? 0 : s.rmax == 4 ? 1 : s.rmax == 2 ? 2 : 3;  // index into the tile statistics
+  const int ri = s.rmax == 4 ? 1 : s.rmax == 2 ? 2 : 3;  // index into the tile statistics
+  const u32 tq = 64 * s.R;
   const u32 tiles = s.adaptive ? (exact_max_tiles ? exact_max_tiles[ri] : adaptive_tiles_bound(max_nq, (u32)s.rmax))
                                : (max_nq + tq - 1) / tq;
   s.tiles = std::max(1u, tiles);
@@ -309,7 +311,7 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   // (a) latency regime: reach TARGET_WAVES with at least 64 train items per split;
   // (b) long scans (1M x 1M): many short waves balance better than few long ones
   //     (profiles/r01/nn2_sweep.txt: 1 -> 24 splits = 0.80 -> 0.95 of the roofline);
-  // (c) float-key tracking wants <= FKEY_MAX_SET train items per split.
+  // (c) a split scans <= FKEY_MAX_SET train items (step tags / float keys).
   u32 sa = 1, sb = 1;
   if (waves < TARGET_WAVES) sa = std::min((u32)((TARGET_WAVES + waves - 1) / waves), std::max(1u, max_nt / 64));
   if (waves < LONG_SCAN_WAVES) sb = std::min((u32)((LONG_SCAN_WAVES + waves - 1) / waves), std::max(1u, max_nt / 4096));
@@ -317,23 +319,25 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   s.splits = std::min(std::max(std::max(sa, sb), std::max(sc, 1u)), 256u);
   if (vs) s.splits = (u32)vs;
   const u32 per = (max_nt + s.splits - 1) / s.splits;
-  s.fkey = per <= FKEY_MAX_SET && !(variant & 0x20000);
-  // bit 25 of the experiment knob: the popcount scan everywhere (A/B runs, parity tests)
-  s.mfma = s.fkey && !(variant & 0x2000000) &&
-           (s.adaptive ? s.rmax <= 4 : (s.R == 1 && !(variant & 0x8000000)));  // bit 27: popcount for short jobs
+  s.fkey = per <= FKEY_MAX_SET;
+  s.mfma = s.fkey && !(variant & KNOB_POPCOUNT) && (s.adaptive || (s.R == 1 && !(variant & KNOB_POPCOUNT_LATENCY)));
   return s;
 }
 
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
-                const u32* d_qlist = nullptr, u32 d_lim = 256, unsigned long long* d_stats = nullptr,
-                int track = -1,  // tracking form: 1 distances, 0 keys, -1 the context's current choice
+                const u32* d_qlist = nullptr, u32 d_lim = 256,
                 AcceptMask acc = AcceptMask{nullptr, 0, nullptr}) {
   const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
-  const u64 blocks = n_jobs * sh.wgs_per_job;
+  u64 blocks = n_jobs * sh.wgs_per_job;
+  dim3 block(256);
+  if (sh.adaptive) {
+    blocks = (sh.uniform ? (n_jobs + 7) / 8 * 8 : n_jobs) * sh.tiles;
+    block = dim3(64);
+  }
   if (blocks > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks);
-  dim3 grid((u32)blocks, sh.splits), block(256);
+  const dim3 grid((u32)blocks, sh.splits);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->profiling) {
     VSM_TRY(ev_pair(c, &e0, &e1));
@@ -342,94 +346,37 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   }
   const u32x4* q = (const u32x4*)qbase;
   const u32x4* t = (const u32x4*)tbase;
-#define VSM_LAUNCH(RR, FF)                                                                          \
-  hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist)
-  // Float-key tracking (train range per split <= 32768): FILL 7 (key construction in the next
-  // chain's filler slots), in the adaptive kernel FILL 8 (FILL 7 + wave-level skip of the
-  // tracking pair); integer keys with a v_mov filler behind every v_bcnt otherwise (FILL 2).
-  // All measured in profiles/r01/scan_variants*.txt.
-  const int fill = !sh.fkey ? 2 : 7;
-  if (sh.adaptive) {
-    // One wave per workgroup: the tiles of a ragged job run 1..8 x as long as each other, and a
-    // 4-wave workgroup can only start when a slot is free on every SIMD at once -- with
-    // one-wave workgroups any freed slot is refilled (tools/ragged_probe.py: 1537 -> 2065 G
-    // comparisons/s at euroc_V1's image sizes, unchanged on uniform ones).  Bit 24 of the
-    // experiment knob: the 4-wave form.
-    const bool w1 = !(c->variant & 0x1000000);
-    dim3 agrid = grid, ablock = block;
-    if (w1) {
-      const u64 blocks1 = (sh.uniform ? (n_jobs + 7) / 8 * 8 : n_jobs) * sh.tiles;
-      if (blocks1 > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks1);
-      agrid = dim3((u32)blocks1, sh.splits);
-      ablock = dim3(64);
-    }
-#define VSM_LAUNCH_A(FF, WW, RR)                                                                     \
-  hipLaunchKernelGGL((scan_kernel_adaptive<FF, WW, RR>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u)
-#define VSM_LAUNCH_M(NN)                                                                               \
-  hipLaunchKernelGGL((mfma_scan_kernel<4, NN>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats, acc)
-#define VSM_LAUNCH_MD(NN)                                                                              \
-  hipLaunchKernelGGL((mfma_scan_kernel<4, NN, 1, 1>), agrid, ablock, 0, c->stream, q, t, d_jobs, (u32)n_jobs, \
-                     sh.splits, split_stride, d_scratch, d_qlist, sh.uniform ? sh.tiles : 0u, d_lim, d_stats, acc)
-    // Tracking form: the context's current choice (see scan_track); knob nibble 20-23 = 14 / 13
-    // forces distances / keys everywhere, 12 = distances in forward scans, keys elsewhere.
-    const int vtr = (c->variant >> 20) & 0xf;
-    const bool track_d = vtr == 14 || vtr == 12 || (vtr != 13 && (track >= 0 ? track == 1 : c->scan_track == 1));
-    if (sh.mfma && w1 && track_d) {
-      if (sh.rmax == 4) VSM_LAUNCH_MD(8);
-      else if (sh.rmax == 2) VSM_LAUNCH_MD(4);
-      else VSM_LAUNCH_MD(2);
-    } else if (sh.mfma && w1) {  // shipped: FP4 matrix-core scan, 32 * NN queries per wave
-      if (sh.rmax == 4) VSM_LAUNCH_M(8);
-      else if (sh.rmax == 2) VSM_LAUNCH_M(4);
-      else VSM_LAUNCH_M(2);
-    } else if (fill == 2) {  // integer keys (a split scans more than 32768 train descriptors)
-      if (sh.rmax == 8 && !w1) VSM_LAUNCH_A(2, 4, 8);
-      else if (sh.rmax == 8) VSM_LAUNCH_A(2, 1, 8);
-      else if (sh.rmax == 4) VSM_LAUNCH_A(2, 1, 4);
-      else if (sh.rmax == 2) VSM_LAUNCH_A(2, 1, 2);
-      else VSM_LAUNCH_A(2, 1, 1);
-    } else if (sh.rmax == 4) {
-      VSM_LAUNCH_A(8, 1, 4);  // shipped: 256-query tiles, FILL 8, one-wave workgroups
-    } else if (sh.rmax == 2) {
-      VSM_LAUNCH_A(8, 1, 2);
-    } else if (sh.rmax == 1) {
-      VSM_LAUNCH_A(8, 1, 1);
-    } else if (w1) {
-      VSM_LAUNCH_A(7, 1, 8);
-    } else {
-      VSM_LAUNCH_A(7, 4, 8);
-    }
-#undef VSM_LAUNCH_A
-#undef VSM_LAUNCH_M
-#undef VSM_LAUNCH_MD
-  } else if (sh.mfma && sh.R == 1) {
-    // 64-query tiles in 4-wave workgroups (the pruned backward pass)
-    const int vtr = (c->variant >> 20) & 0xf;
-    // query lists (pruned backward pass) follow the forward scan's form; one short pair keeps the
-    // keys (the index recovery of the distance form costs it 3 us of 56)
-    if (vtr == 14 || (vtr != 13 && vtr != 12 && (track >= 0 ? track == 1 : (d_qlist && c->scan_track == 1))))
-      hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4, 1>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
-                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr, AcceptMask{nullptr, 0, nullptr});
-    else
-      hipLaunchKernelGGL((mfma_scan_kernel<4, 2, 4>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs,
-                         sh.splits, split_stride, d_scratch, d_qlist, 0u, d_lim, (unsigned long long*)nullptr, AcceptMask{nullptr, 0, nullptr});
-  } else
-  // fixed tiles: the skip test (FILL 8) pays at 1, 2 and 4 queries per lane, not at 8
-  switch (sh.R * 16 + (fill == 7 && sh.R < 8 ? 8 : fill)) {
-    case 16 + 2: VSM_LAUNCH(1, 2); break;
-    case 16 + 8: VSM_LAUNCH(1, 8); break;
-    case 32 + 2: VSM_LAUNCH(2, 2); break;
-    case 32 + 8: VSM_LAUNCH(2, 8); break;
-    case 64 + 2: VSM_LAUNCH(4, 2); break;
-    case 64 + 8: VSM_LAUNCH(4, 8); break;
-    case 128 + 2: VSM_LAUNCH(8, 2); break;
-    case 128 + 7: VSM_LAUNCH(8, 7); break;
-    default: return fail(VSM_ERR_INVALID, "unsupported R=%d", sh.R);
+  const u32 grouped = sh.uniform ? sh.tiles : 0u;
+  // popcount scans: float keys with the skip test (FILL 8) unless a split scans more than 32768
+  // rows or the knob asks for integer keys (FILL 2)
+  const bool fill8 = sh.fkey && !(c->variant & KNOB_INT_KEYS);
+#define VSM_LAUNCH_M(NN, WW)                                                                                       \
+  hipLaunchKernelGGL((mfma_scan_kernel<NN, WW>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
+                     split_stride, d_scratch, d_qlist, grouped, d_lim, acc)
+#define VSM_LAUNCH_A(FF, RR)                                                                                        \
+  hipLaunchKernelGGL((scan_kernel_adaptive<FF, RR>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
+                     split_stride, d_scratch, d_qlist, grouped)
+#define VSM_LAUNCH(RR, FF)                                                                                     \
+  hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
+                     split_stride, d_scratch, d_qlist)
+  if (sh.adaptive && sh.mfma) {  // shipped: FP4 matrix-core scan, 32 * NB queries per wave
+    if (sh.rmax == 4) VSM_LAUNCH_M(8, 1);
+    else if (sh.rmax == 2) VSM_LAUNCH_M(4, 1);
+    else VSM_LAUNCH_M(2, 1);
+  } else if (sh.adaptive) {
+    if (sh.rmax == 4) { if (fill8) VSM_LAUNCH_A(8, 4); else VSM_LAUNCH_A(2, 4); }
+    else if (sh.rmax == 2) { if (fill8) VSM_LAUNCH_A(8, 2); else VSM_LAUNCH_A(2, 2); }
+    else { if (fill8) VSM_LAUNCH_A(8, 1); else VSM_LAUNCH_A(2, 1); }
+  } else if (sh.mfma) {  // 64-query tiles in 4-wave workgroups: one stereo pair, the pruned backward pass
+    VSM_LAUNCH_M(2, 4);
+  } else if (sh.R == 4) {
+    if (fill8) VSM_LAUNCH(4, 8); else VSM_LAUNCH(4, 2);
+  } else {
+    if (fill8) VSM_LAUNCH(1, 8); else VSM_LAUNCH(1, 2);
   }
 #undef VSM_LAUNCH
+#undef VSM_LAUNCH_A
+#undef VSM_LAUNCH_M
   HIP_TRY(hipGetLastError());
   if (c->profiling) HIP_TRY(hipEventRecord(e1, c->stream));
   c->scan_launches[kind]++;
@@ -451,8 +398,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   u64* d_running = (u64*)c->misc.p;
   u64* d_comps = d_running + 1;
   u32* d_bad = (u32*)(d_running + 3);
-  unsigned long long* d_stats = (unsigned long long*)(d_running + 4);  // [steps][steps off the common path]
-  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 48, c->stream));
+  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 32, c->stream));
   if (n_pairs == 0) {
     HIP_TRY(hipMemsetAsync(d_out_offsets, 0, sizeof(u64), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -460,11 +406,10 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     return VSM_OK;
   }
   const u32 stride = std::max(64u, round_up(max_n, 64));
-  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, d_desc == c->db ? c->max_tiles : nullptr,
-                                    d_desc == c->db ? c->uniform_tiles : nullptr,
-                                    d_desc == c->db ? c->avg_tiles : nullptr,
-                                    std::min<u64>(n_pairs, 32768),  // forward jobs of one chunk
-                                    c->scan_track == 1 && c->last_slow_share > 0.5);
+  const bool own_db = d_desc == c->db;
+  const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, own_db ? c->max_tiles : nullptr,
+                                    own_db ? c->uniform_tiles : nullptr, own_db ? c->avg_tiles : nullptr,
+                                    std::min<u64>(n_pairs, 32768));  // forward jobs of one chunk
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
@@ -475,14 +420,13 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   VSM_TRY(c->scratch.reserve(split_stride * sh.splits * sizeof(uint2)));
   VSM_TRY(c->jobs.reserve(chunk * 2 * sizeof(Job)));
   VSM_TRY(c->counts.reserve(chunk * sizeof(u32)));
-  // Pruned backward pass (nominate_kernel): only for unsplit scans and images that
-  // fit the LDS bitmap; bit 16 of the experiment knob turns it off for A/B runs.
-  const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & 0x10000);
+  // Pruned backward pass (nominate_kernel): only for unsplit scans and images that fit the LDS bitmap.
+  const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & KNOB_NO_PRUNE);
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
   if (prune) VSM_TRY(c->flist.reserve(chunk * stride * sizeof(u32)));
   // accept masks (one bit per forward row) and the accept table on the device, for the matrix-core
   // forward scan's epilogue; the popcount scans do not write masks (nominate_kernel then reads every row)
-  const bool masks = prune && sh.mfma && sh.adaptive && !(c->variant & 0x1000000);
+  const bool masks = prune && sh.mfma && sh.adaptive;
   AcceptMask acc{nullptr, 0, nullptr};
   if (masks) {
     VSM_TRY(c->accmask.reserve(chunk * (stride / 32) * sizeof(u32)));
@@ -491,21 +435,20 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     acc = AcceptMask{(const uint16_t*)c->lut.p, prm.threshold, (u32*)c->accmask.p};
   }
   // Backward jobs of the pruned pass scan ragged nominated lists whose lengths only the device
-  // knows: fixed 64-query tiles (matrix-core scan: 32 * 2 queries per wave, 4-wave workgroups).
+  // knows: fixed 64-query tiles in 4-wave workgroups (matrix-core scan: 32 * 2 queries per wave).
   // Adaptive tiles were measured here twice and do not pay: with the popcount scan a sparse
   // batch went 0.45 -> 1.18 ms per launch and a dense one 4.4 -> 5.4 ms; with the matrix-core
   // scan (256-query tiles) sparse 0.137 -> 0.153 ms, dense 1.59 -> 1.62 ms.  One looping workgroup
   // per job instead of eight mostly idle ones: sparse 0.144 -> 0.172 ms, dense 1.50 -> 1.36 ms.
   ScanShape shb = sh;
   shb.adaptive = false;
-  const int vbr = (c->variant >> 20) & 0xf;  // experiment knob: backward R override
-  shb.R = (vbr == 1 || vbr == 2 || vbr == 4 || vbr == 8) ? vbr : 1;
-  shb.wgs_per_job = std::max(1u, ((max_n + 64 * shb.R - 1) / (64 * shb.R) + 3) / 4);
-  // bits 25 / 26 of the experiment knob: popcount scan everywhere / in the backward pass
-  shb.mfma = shb.R == 1 && sh.fkey && !(c->variant & (0x2000000 | 0x4000000));
+  shb.R = 1;
+  shb.wgs_per_job = std::max(1u, ((max_n + 63) / 64 + 3) / 4);
+  shb.mfma = sh.fkey && !(c->variant & (KNOB_POPCOUNT | KNOB_POPCOUNT_BACKWARD));
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
   u32* d_counts = (u32*)c->counts.p;
+  const u32x4* desc = (const u32x4*)d_desc;
   const u32 d_lim = accept_limit(prm);
 
   for (u64 first = 0; first < n_pairs; first += chunk) {
@@ -515,27 +458,27 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        prune ? 1u : 2u);
     HIP_TRY(hipGetLastError());
     if (prune) {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats, -1, acc));
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, acc));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1, (const u32*)acc.mask);
+                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1, (const u32*)acc.mask, desc,
+                         sh.mfma ? 1u : 0u);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
-    } else {
-      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, d_stats));
-    }
-    if (sh.splits > 1) {
-      const u32 n_entries = n * 2 * stride;
-      hipLaunchKernelGGL(merge_splits_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, c->stream,
-                         d_scratch, n_entries, sh.splits, (u32)split_stride);
-      HIP_TRY(hipGetLastError());
-    }
-    if (prune)
       hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
-                         (const u32*)c->flist.p, stride, prm, d_counts);
-    else
+                         (const u32*)c->flist.p, stride, prm, d_counts, desc, shb.mfma ? 1u : 0u);
+    } else {
+      VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
+      if (sh.splits > 1 || sh.mfma) {
+        const u32 n_entries = n * 2 * stride;
+        hipLaunchKernelGGL(merge_refine_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, c->stream,
+                           (const Job*)d_jobs, n, stride, d_scratch, sh.splits, (u32)split_stride, desc, prm,
+                           sh.mfma ? 1u : 0u);
+        HIP_TRY(hipGetLastError());
+      }
       hipLaunchKernelGGL(count_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
                          1u, (u32)split_stride, prm, d_counts);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, d_counts, n,
                        d_out_offsets, first, d_running);
@@ -552,18 +495,9 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     u64 total, comps_fwd, comps_bwd;
     u32 bad;
     u32 pad;
-    u64 steps, slow;
   } h;
-  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 48, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, c->misc.p, 32, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  // Next call's tracking form.  A step off the common path costs ~450 cycles with keys and ~100
-  // with distances, whose common path is ~15 % slower: break-even near 8 % of the steps.
-  if (h.steps >= 1024) {  // a 1-in-64 sample of the workgroups
-    const double share = (double)h.slow / (double)h.steps;
-    c->last_slow_share = share;
-    if (share > 0.10) c->scan_track = 1;
-    else if (share < 0.05) c->scan_track = 0;
-  }
   if (c->profiling) VSM_TRY(stats_collect(c));
   c->scan_comps[0] = h.comps_fwd;
   c->scan_comps[1] = h.comps_bwd;
@@ -579,13 +513,22 @@ int check_ctx(vsm_ctx* c) {
   return VSM_OK;
 }
 
-int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
+int check_offsets(const uint32_t* offsets, size_t n_img) {
   if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
   if (n_img >= 0xffffffffull) return fail(VSM_ERR_INVALID, "too many images");
+  for (size_t i = 0; i < n_img; i++) {
+    if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
+    if (offsets[i + 1] - offsets[i] > VSM_MAX_SET)
+      return fail(VSM_ERR_INVALID, "image %zu with %u descriptors exceeds VSM_MAX_SET", i, offsets[i + 1] - offsets[i]);
+  }
+  return VSM_OK;
+}
+
+int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img) {
+  VSM_TRY(check_offsets(offsets, n_img));
   u32 max_n = 0, max_tiles[4] = {0, 0, 0, 0}, min_tiles[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   double sum_tiles[4] = {0, 0, 0, 0};
   for (size_t i = 0; i < n_img; i++) {
-    if (offsets[i + 1] < offsets[i]) return fail(VSM_ERR_INVALID, "offsets not ascending at image %zu", i);
     max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
     for (int ri = 0; ri < 4; ri++) {
       const u32 tl = adaptive_tiles(offsets[i + 1] - offsets[i], 8u >> ri);
@@ -594,7 +537,6 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
       sum_tiles[ri] += tl;
     }
   }
-  if (max_n > VSM_MAX_SET) return fail(VSM_ERR_INVALID, "image with %u descriptors exceeds VSM_MAX_SET", max_n);
   if (n_img && !d_desc && offsets[n_img] != 0) return fail(VSM_ERR_INVALID, "null descriptor pointer");
   VSM_TRY(c->d_img_off.reserve((n_img + 1) * sizeof(u32)));
   HIP_TRY(hipMemcpyAsync(c->d_img_off.p, offsets, (n_img + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
@@ -670,13 +612,6 @@ int vsm_set_profiling(vsm_ctx* c, int enabled) {
   return VSM_OK;
 }
 
-int vsm_scan_tracking(vsm_ctx* c, int* mode, double* slow_share) {
-  if (!c) return fail(VSM_ERR_INVALID, "null context");
-  if (mode) *mode = c->scan_track;
-  if (slow_share) *slow_share = c->last_slow_share;
-  return VSM_OK;
-}
-
 int vsm_accept_limit(int threshold, double dist_2_best) {
   AcceptParams prm;
   make_accept(threshold, dist_2_best, &prm);
@@ -713,9 +648,13 @@ int vsm_db_upload(vsm_ctx* c, const uint64_t* desc, const uint32_t* offsets, siz
   VSM_TRY(check_ctx(c));
   std::lock_guard<std::recursive_mutex> lk(c->mu);
   DeviceGuard g(c->device);
-  if (!offsets) return fail(VSM_ERR_INVALID, "null offsets");
+  VSM_TRY(check_offsets(offsets, n_img));  // before the old database is touched
   const size_t total = offsets[n_img];
   if (total && !desc) return fail(VSM_ERR_INVALID, "null descriptor pointer");
+  // From here on the old database is gone (reserve may free it, the copy overwrites it): forget it,
+  // so that a failure below leaves "no database", not pointers into freed or mismatched memory.
+  c->db = nullptr;
+  c->img_off.clear();
   VSM_TRY(c->db_owned.reserve(std::max<size_t>(total * DESC_BYTES, 256)));
   if (total) HIP_TRY(hipMemcpyAsync(c->db_owned.p, desc, total * DESC_BYTES, hipMemcpyHostToDevice, c->stream));
   return set_db(c, c->db_owned.p, offsets, n_img);
@@ -810,9 +749,10 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
                       2ull * n1 * n2, nullptr, accept_limit(prm)));
   u64* d_off = (u64*)c->w_out.p;
   int2* d_out = (int2*)((char*)c->w_out.p + 16);
-  if (sh.splits > 1)
-    hipLaunchKernelGGL(merge_splits_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream,
-                       (uint2*)c->scratch.p, split_stride, sh.splits, split_stride);
+  if (sh.splits > 1 || sh.mfma)
+    hipLaunchKernelGGL(merge_refine_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream, d_jobs, 1u,
+                       stride, (uint2*)c->scratch.p, sh.splits, split_stride, (const u32x4*)c->stage.p, prm,
+                       sh.mfma ? 1u : 0u);
   hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
                      split_stride, prm, d_off, d_out, (u64)nmin);
   HIP_TRY(hipGetLastError());
@@ -845,17 +785,18 @@ int vsm_nn2_device(vsm_ctx* c, const void* d_query, size_t nq, const void* d_tra
   if ((u64)split_stride * sh.splits > 0xffffffffull) return fail(VSM_ERR_INVALID, "scratch index overflow");
   VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
   VSM_TRY(c->jobs.reserve(sizeof(Job)));
-  VSM_TRY(c->pin.reserve(sizeof(Job)));
-  Job j = {0, (u32)nq, 0, (u32)nt, 0, NO_QLIST, 0, 0};
-  memcpy(c->pin.p, &j, sizeof j);
-  HIP_TRY(hipMemcpyAsync(c->jobs.p, c->pin.p, sizeof j, hipMemcpyHostToDevice, c->stream));
-  // everything is tracked here (start distance 256): the distance form is the faster one
-  // (1M x 1M: 93 ms against 120 ms with keys)
-  VSM_TRY(launch_scan(c, d_query, nt ? d_train : d_query, (const Job*)c->jobs.p, 1, sh, split_stride,
-                      (uint2*)c->scratch.p, (u64)nq * nt, nullptr, 256, nullptr, 1));
+  // The job goes to the device as a kernel argument: this entry point returns before its work has
+  // run, and a host staging buffer could be overwritten by the next call before it was copied.
+  const Job j = {0, (u32)nq, 0, (u32)nt, 0, NO_QLIST, 0, 0};
+  hipLaunchKernelGGL(set_jobs_kernel, dim3(1), dim3(64), 0, c->stream, (Job*)c->jobs.p, j, j, 1u);
+  HIP_TRY(hipGetLastError());
+  const void* d_tr = nt ? d_train : d_query;
+  VSM_TRY(launch_scan(c, d_query, d_tr, (const Job*)c->jobs.p, 1, sh, split_stride, (uint2*)c->scratch.p,
+                      (u64)nq * nt, nullptr, 256));
   hipLaunchKernelGGL(finalize_nn2_kernel, dim3((u32)((nq + 255) / 256)), dim3(256), 0, c->stream,
                      (const uint2*)c->scratch.p, (u32)nq, sh.splits, split_stride, (int*)d_best_idx,
-                     (int*)d_best_dist, (int*)d_second_dist);
+                     (int*)d_best_dist, (int*)d_second_dist, (const u32x4*)d_query, (const u32x4*)d_tr, (u32)nt,
+                     sh.mfma ? 1u : 0u);
   HIP_TRY(hipGetLastError());
   if (c->profiling) {
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -27,7 +27,7 @@ SYMBOLS = (
     "vsm_match_pair", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
     "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
     "vsm_set_profiling",
-    "vsm_set_variant", "vsm_accept_limit", "vsm_scan_tracking",
+    "vsm_set_variant", "vsm_accept_limit",
     "vsm_match_landmarks",
     "vsm_orb_describe", "vsm_orb_angles", "vsm_orb_descriptors",
     "vsm_detect_keypoints", "vsm_good_features_to_track", "vsm_detect_and_describe",
@@ -73,7 +73,6 @@ def lib():
             L.vsm_last_scan_stats_kind.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
-            L.vsm_scan_tracking.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
             L.vsm_accept_limit.argtypes = [C.c_int, C.c_double]
             L.vsm_accept_limit.restype = C.c_int
             L.vsm_orb_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp, _vp]
@@ -354,13 +353,6 @@ class Matcher:
 
     def set_variant(self, v: int):
         _check(lib().vsm_set_variant(self._h, int(v)))
-
-    def scan_tracking(self):
-        """(mode the next batched call will use: 0 float keys / 1 distances, share of 32 x 32 steps
-        of the last batched call that left the common path)."""
-        mode, share = C.c_int(0), C.c_double(0)
-        _check(lib().vsm_scan_tracking(self._h, C.byref(mode), C.byref(share)))
-        return mode.value, share.value
 
     def last_scan_stats(self, kind: int | None = None):
         """kind None = all scan launches of the last call, 0 = full/forward, 1 = pruned backward."""
