@@ -86,6 +86,28 @@ int vsm_match_pair(vsm_ctx* ctx, const uint64_t* d1, size_t n1, const uint64_t* 
                    size_t cap_pairs, size_t* out_count);
 
 /*
+ * vsm_match_pair for callers that cannot allocate -- code under HIP graph capture, tight serving
+ * loops (one call per odometry keyframe, src/odometry.cpp:814), harnesses that forbid hipMalloc.
+ * It has no counterpart in the reference.  Same result as vsm_match_pair, but: every pointer is a
+ * DEVICE pointer (d_d1[n1][4], d_d2[n2][4] uint64 in; d_out_pairs[cap_pairs][2] int32 and
+ * d_out_count[1] uint64 out); it only enqueues kernels on vsm_stream() and returns -- the caller
+ * synchronises the stream before reading the outputs; it calls no hipMalloc / hipFree / hipMemcpy
+ * and creates no events (vsm_set_profiling is ignored for it).  Its scratch (two jobs and the
+ * partial scan results of the train splits) is a static device array of 4 MiB + 256 B per GPU:
+ *   - at most 8192 descriptors per side; larger sets (or a knob-forced split count whose results do
+ *     not fit) fail with VSM_ERR_INVALID and a message, nothing is enqueued;
+ *   - every call on a GPU, from any context, uses that GPU's one array: calls that overlap on one GPU
+ *     race.  Calls on the same context are ordered by its stream; with several contexts on one GPU
+ *     wait for one call to finish before starting the next.  Nothing in the array has to be zero
+ *     (every word that is read was written by the same call).
+ * *d_out_count = number of matches, which may exceed cap_pairs: then only the first cap_pairs are
+ * stored (min(n1, n2) always suffices).  No VSM_ERR_CAPACITY: the host does not see the count.
+ */
+int vsm_match_pair_noalloc(vsm_ctx* ctx, const void* d_d1, size_t n1, const void* d_d2, size_t n2,
+                           int threshold, double dist_2_best, void* d_out_pairs, size_t cap_pairs,
+                           void* d_out_count);
+
+/*
  * One direction of the scan, keypoints.h:256-290 (== 305-339 with the roles
  * swapped), before the accept test: for each query the lowest-index nearest
  * train descriptor, its distance and the second smallest distance.  best_idx

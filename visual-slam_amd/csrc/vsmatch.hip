@@ -104,6 +104,17 @@ struct PinBuf {
 };
 
 constexpr size_t DESC_BYTES = 32;
+
+// Scratch of vsm_match_pair_noalloc: a file-scope device array, so that the entry point needs no
+// hipMalloc.  Every GPU the library runs on holds its own copy (4 MiB + 256 B) at its own address
+// until the process ends; vsm_create asks for that address (hipGetSymbolAddress, with the
+// context's device current) and host code only ever uses the pointer it got -- the array's NAME is
+// a host-side stand-in, not a device address.  Layout: [Job forward | Job backward | pad to 256 |
+// scan results: splits x 2 x stride uint2].
+constexpr size_t NOALLOC_MAX_SET = 8192;                   // descriptors per side
+constexpr size_t NOALLOC_RESULT_BYTES = (size_t)4 << 20;   // 16 splits x 2 x 8192 x 8 B = 2 MiB at the maximum
+constexpr size_t NOALLOC_BYTES = 256 + NOALLOC_RESULT_BYTES;
+static __device__ __align__(256) unsigned char g_noalloc_scratch[NOALLOC_BYTES];
 constexpr size_t SCRATCH_BUDGET = (size_t)2 << 30;  // scan results per chunk of pairs
 constexpr u32 TARGET_WAVES = 4096;                  // below this the train range is split
 constexpr u32 LONG_SCAN_WAVES = 98304;              // long scans are split until a launch has this many waves
@@ -131,6 +142,7 @@ struct vsm_ctx {
   DevBuf voc;          // vocabulary tree (vsm_voc_upload)
   size_t voc_nodes = 0, voc_off[6] = {0, 0, 0, 0, 0, 0};
   PinBuf pin, pin_image;
+  void* noalloc = nullptr;  // this device's copy of g_noalloc_scratch (hipGetSymbolAddress in vsm_create)
   // measurement
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -327,7 +339,8 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
 int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_jobs, u64 n_jobs,
                 const ScanShape& sh, u32 split_stride, uint2* d_scratch, u64 comps,
                 const u32* d_qlist = nullptr, u32 d_lim = 256,
-                AcceptMask acc = AcceptMask{nullptr, 0, nullptr}) {
+                AcceptMask acc = AcceptMask{nullptr, 0, nullptr},
+                bool timing = true) {  // false: never create events (vsm_match_pair_noalloc)
   const int kind = d_qlist ? 1 : 0;
   if (n_jobs == 0) return VSM_OK;
   u64 blocks = n_jobs * sh.wgs_per_job;
@@ -339,7 +352,8 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   if (blocks > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks);
   const dim3 grid((u32)blocks, sh.splits);
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->profiling) {
+  const bool timed = c->profiling && timing;
+  if (timed) {
     VSM_TRY(ev_pair(c, &e0, &e1));
     c->ev_kind.push_back(kind);
     HIP_TRY(hipEventRecord(e0, c->stream));
@@ -378,7 +392,7 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #undef VSM_LAUNCH_A
 #undef VSM_LAUNCH_M
   HIP_TRY(hipGetLastError());
-  if (c->profiling) HIP_TRY(hipEventRecord(e1, c->stream));
+  if (timed) HIP_TRY(hipEventRecord(e1, c->stream));
   c->scan_launches[kind]++;
   c->scan_comps[kind] += comps;
   return VSM_OK;
@@ -472,7 +486,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
       if (sh.splits > 1 || sh.mfma) {
         const u32 n_entries = n * 2 * stride;
         hipLaunchKernelGGL(merge_refine_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, c->stream,
-                           (const Job*)d_jobs, n, stride, d_scratch, sh.splits, (u32)split_stride, desc, prm,
+                           (const Job*)d_jobs, n, stride, d_scratch, sh.splits, (u32)split_stride, desc, desc, prm,
                            sh.mfma ? 1u : 0u);
         HIP_TRY(hipGetLastError());
       }
@@ -582,6 +596,13 @@ int vsm_create(int device, vsm_ctx** out) {
   if (e != hipSuccess) {
     delete c;
     return fail(VSM_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+  }
+  // device address of the static scratch of vsm_match_pair_noalloc ON THIS DEVICE (current here)
+  e = hipGetSymbolAddress(&c->noalloc, HIP_SYMBOL(g_noalloc_scratch));
+  if (e != hipSuccess || !c->noalloc) {
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail(VSM_ERR_HIP, "hipGetSymbolAddress(g_noalloc_scratch) failed on device %d: %s", device, hipGetErrorString(e));
   }
   *out = c;
   return VSM_OK;
@@ -751,10 +772,10 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   int2* d_out = (int2*)((char*)c->w_out.p + 16);
   if (sh.splits > 1 || sh.mfma)
     hipLaunchKernelGGL(merge_refine_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream, d_jobs, 1u,
-                       stride, (uint2*)c->scratch.p, sh.splits, split_stride, (const u32x4*)c->stage.p, prm,
-                       sh.mfma ? 1u : 0u);
+                       stride, (uint2*)c->scratch.p, sh.splits, split_stride, (const u32x4*)c->stage.p,
+                       (const u32x4*)c->stage.p, prm, sh.mfma ? 1u : 0u);
   hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
-                     split_stride, prm, d_off, d_out, (u64)nmin);
+                     split_stride, prm, d_off, d_out, (u64)nmin, 1u);
   HIP_TRY(hipGetLastError());
   char* hd = h + up_bytes;
   HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -766,6 +787,56 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   *out_count = count;
   if (count > cap_pairs) return fail(VSM_ERR_CAPACITY, "%zu matches need more than cap_pairs=%zu", count, cap_pairs);
   if (count) memcpy(out_pairs, hd + 16, count * 8);
+  return VSM_OK;
+}
+
+int vsm_match_pair_noalloc(vsm_ctx* c, const void* d_d1, size_t n1, const void* d_d2, size_t n2, int threshold,
+                           double dist_2_best, void* d_out_pairs, size_t cap_pairs, void* d_out_count) {
+  VSM_TRY(check_ctx(c));
+  if (!d_out_count) return fail(VSM_ERR_INVALID, "null d_out_count");
+  if ((n1 && !d_d1) || (n2 && !d_d2)) return fail(VSM_ERR_INVALID, "null descriptor pointer");
+  if (cap_pairs && !d_out_pairs) return fail(VSM_ERR_INVALID, "null d_out_pairs with non-zero capacity");
+  if (n1 > NOALLOC_MAX_SET || n2 > NOALLOC_MAX_SET)
+    return fail(VSM_ERR_INVALID, "vsm_match_pair_noalloc takes at most %zu descriptors per side (got %zu x %zu): "
+                "its scratch is a fixed device array; use vsm_match_pair", NOALLOC_MAX_SET, n1, n2);
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (n1 == 0 || n2 == 0) {  // keypoints.h:251: matches.clear(), nothing to add
+    HIP_TRY(hipMemsetAsync(d_out_count, 0, sizeof(u64), c->stream));
+    return VSM_OK;
+  }
+  stats_reset(c);
+  AcceptParams prm;
+  make_accept(threshold, dist_2_best, &prm);
+  const u32 nmax = (u32)std::max(n1, n2);
+  const u32 stride = std::max(64u, round_up(nmax, 64));
+  const ScanShape sh = choose_shape(2, nmax, nmax, c->variant);
+  const u32 split_stride = 2 * stride;
+  const size_t need = (size_t)split_stride * sh.splits * sizeof(uint2);
+  if (need > NOALLOC_RESULT_BYTES)
+    return fail(VSM_ERR_INVALID, "vsm_match_pair_noalloc: %u train splits of %zu x %zu need %zu bytes of scan results, "
+                "the fixed scratch holds %zu", sh.splits, n1, n2, need, NOALLOC_RESULT_BYTES);
+  // everything below only enqueues kernels on the context's stream: no allocation, no copy, no wait
+  Job* d_jobs = (Job*)c->noalloc;
+  uint2* d_scratch = (uint2*)((char*)c->noalloc + 256);
+  const Job jf = {0, (u32)n1, 0, (u32)n2, 0, NO_QLIST, 0, 0};
+  const Job jb = {0, (u32)n2, 0, (u32)n1, stride, NO_QLIST, 0, 0};
+  hipLaunchKernelGGL(set_jobs_kernel, dim3(1), dim3(64), 0, c->stream, d_jobs, jf, jb, 2u);
+  HIP_TRY(hipGetLastError());
+  const u32 d_lim = accept_limit(prm);
+  // the two sets are separate buffers: one launch per direction (vsm_match_pair stages both sets
+  // into one buffer and scans both directions in one launch)
+  VSM_TRY(launch_scan(c, d_d1, d_d2, d_jobs, 1, sh, split_stride, d_scratch, (u64)n1 * n2, nullptr, d_lim,
+                      AcceptMask{nullptr, 0, nullptr}, false));
+  VSM_TRY(launch_scan(c, d_d2, d_d1, d_jobs + 1, 1, sh, split_stride, d_scratch, (u64)n1 * n2, nullptr, d_lim,
+                      AcceptMask{nullptr, 0, nullptr}, false));
+  if (sh.splits > 1 || sh.mfma)
+    hipLaunchKernelGGL(merge_refine_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream, (const Job*)d_jobs,
+                       1u, stride, d_scratch, sh.splits, split_stride, (const u32x4*)d_d1, (const u32x4*)d_d2, prm,
+                       sh.mfma ? 1u : 0u);
+  hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(256), 0, c->stream, (const Job*)d_jobs, (const uint2*)d_scratch,
+                     split_stride, prm, (u64*)d_out_count, (int2*)d_out_pairs, (u64)cap_pairs, 0u);
+  HIP_TRY(hipGetLastError());
   return VSM_OK;
 }
 

@@ -411,7 +411,8 @@ __device__ __forceinline__ void load_lut(uint16_t* lut, const AcceptParams& prm)
 // chunk: entry e = pair e / (2 stride), direction (e / stride) & 1, query e % stride.
 __global__ __launch_bounds__(256) void merge_refine_kernel(const Job* __restrict__ jobs, u32 n_pairs, u32 stride,
                                                            uint2* __restrict__ scratch, u32 splits, u32 split_stride,
-                                                           const u32x4* __restrict__ desc, AcceptParams prm, u32 refine) {
+                                                           const u32x4* __restrict__ desc_1, const u32x4* __restrict__ desc_2,
+                                                           AcceptParams prm, u32 refine) {
   __shared__ uint16_t lut[260];
   load_lut(lut, prm);
   const u32 e = blockIdx.x * 256 + threadIdx.x;
@@ -424,7 +425,11 @@ __global__ __launch_bounds__(256) void merge_refine_kernel(const Job* __restrict
   if (refine && accepted(v, lut, prm.threshold, idx)) {
     const u32 col = q;  // unpruned jobs have no query list
     const u32 per = (job.nt + splits - 1) / splits;
-    v.y = refine_second(desc + 2 * (size_t)(job.q_off + col), desc + 2 * (size_t)job.t_off, job.nt, per, v) << IDX_BITS;
+    // forward jobs take their queries from desc_1 and their train rows from desc_2, backward jobs the
+    // other way round (one database: the same pointer twice)
+    const u32x4* dq = dir ? desc_2 : desc_1;
+    const u32x4* dt = dir ? desc_1 : desc_2;
+    v.y = refine_second(dq + 2 * (size_t)(job.q_off + col), dt + 2 * (size_t)job.t_off, job.nt, per, v) << IDX_BITS;
   }
   scratch[e] = v;
 }
@@ -533,12 +538,12 @@ __global__ __launch_bounds__(256) void fill_kernel(const Job* __restrict__ jobs,
 
 // Single pair (vsm_match_pair, the odometry / match_stereo call): accept test, cross-check and
 // ordered emission in ONE single-workgroup kernel instead of count + scan_counts + fill (three
-// launches, ~22 us of a ~80 us call).  out_count[0] = number of matches; pairs from out_pairs[0].
+// launches, ~22 us of a ~80 us call).  out_count[count_slot] = number of matches; pairs from out_pairs[0].
 // jobs[0] = forward job, jobs[1] = backward job; scratch holds the merged results (splits folded).
 __global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ jobs,
                                                         const uint2* __restrict__ scratch, u32 split_stride,
                                                         AcceptParams prm, u64* __restrict__ out_count,
-                                                        int2* __restrict__ out_pairs, u64 cap_pairs) {
+                                                        int2* __restrict__ out_pairs, u64 cap_pairs, u32 count_slot) {
   __shared__ uint16_t lut[260];
   __shared__ u32 wave_cnt[4];
   load_lut(lut, prm);
@@ -565,8 +570,9 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out_count[0] = 0;
-    out_count[1] = done;  // same layout as the offsets pair {0, count} the host reads
+    // count_slot 1: the offsets pair {0, count} vsm_match_pair reads back; 0: the count alone
+    if (count_slot) out_count[0] = 0;
+    out_count[count_slot] = done;
   }
 }
 

@@ -24,7 +24,7 @@ VSM_MAX_SET = 1 << 23
 # every symbol include/vsmatch.h declares
 SYMBOLS = (
     "vsm_version", "vsm_last_error", "vsm_create", "vsm_destroy", "vsm_stream",
-    "vsm_match_pair", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
+    "vsm_match_pair", "vsm_match_pair_noalloc", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
     "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
     "vsm_set_profiling",
     "vsm_set_variant", "vsm_accept_limit",
@@ -63,6 +63,7 @@ def lib():
             L.vsm_stream.argtypes = [_vp]
             L.vsm_stream.restype = _vp
             L.vsm_match_pair.argtypes = [_vp, _vp, _sz, _vp, _sz, C.c_int, C.c_double, _vp, _sz, C.POINTER(_sz)]
+            L.vsm_match_pair_noalloc.argtypes = [_vp, _vp, _sz, _vp, _sz, C.c_int, C.c_double, _vp, _sz, _vp]
             L.vsm_nn2.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]
             L.vsm_nn2_device.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]
             L.vsm_db_upload.argtypes = [_vp, _vp, _vp, _sz]
@@ -149,6 +150,13 @@ class Matcher:
         _check(lib().vsm_match_pair(self._h, _ptr(d1), len(d1), _ptr(d2), len(d2), int(threshold),
                                     float(dist_2_best), _ptr(out), cap, C.byref(n)))
         return out[: n.value].copy()
+
+    def match_pair_noalloc(self, d_d1: int, n1: int, d_d2: int, n2: int, threshold: int, dist_2_best: float,
+                           d_out_pairs: int, cap: int, d_out_count: int):
+        """vsm_match_pair_noalloc: raw device pointers in and out, only enqueues (synchronise
+        `stream` before reading), allocates nothing; at most 8192 descriptors per side."""
+        _check(lib().vsm_match_pair_noalloc(self._h, _vp(d_d1), n1, _vp(d_d2), n2, int(threshold), float(dist_2_best),
+                                            _vp(d_out_pairs), int(cap), _vp(d_out_count)))
 
     # -- keypoints.h:256-290 --------------------------------------------------
     def nn2(self, query, train):
