@@ -107,8 +107,8 @@ constexpr int GROUP_D_256 = 0x41000000;   // bits of 8.0 = D' of distance 256
 // One tile = 32 * NB queries of a job (lane l: column l & 31 of each block of 32, half l >> 5 of
 // the k range) against the split's share of the train range, 32 rows at a time.  Software
 // pipeline over (32 train rows, query block) steps: the four MFMAs of the next step are issued
-// before the minimum tree of the current one (two accumulator sets); sched_group_barriers fix the
-// issue order MFMA MFMA 4 x VALU MFMA 4 x VALU MFMA.
+// before the minimum tree of the current one (two accumulator sets); sched_group_barriers
+// interleave them, three VALU instructions behind each MFMA.
 template <int NB>
 __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
                                                  const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
@@ -137,15 +137,20 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
   for (int b = 0; b < NB; b++) best[b] = second[b] = init;
 
   if (t1 > t0) {
-    const u32x4* tr = tbase + 2 * (size_t)job.t_off + h;
-    const u32 last = t1 - 1;
+    // train rows: a wave-uniform base and a 32-bit byte offset per lane (row c of the step, half h),
+    // clamped to the last row of the range (rows past the end are loaded again, never used)
+    const char* tr = (const char*)(tbase + 2 * (size_t)job.t_off);
+    const u32 last_off = (t1 - 1) * 32u + h * 16u;
+    auto row = [&](u32 off) { return *(const u32x4*)(tr + min(off, last_off)); };
+    u32 off = (t0 + c) * 32u + h * 16u;  // this lane's row of the current step
     // start values of the accumulators: 6.0 + i ulp, kept in registers for the whole scan
     f32x16 zero;
 #pragma unroll
     for (int i = 0; i < 16; i++) zero[i] = __int_as_float(0x40C00000 + i);
     asm volatile("" : "+v"(zero));
-    u32x4 w = tr[2 * (size_t)min(t0 + c, last)];
-    u32x4 wn = tr[2 * (size_t)min(t0 + 32 + c, last)];
+    u32x4 w = row(off);
+    u32x4 wn = row(off + 1024u);  // the step after: in flight while the current one is expanded
+    off += 2048u;
     i32x8 A[4];
     A[0] = expand_bits_r(w.x, m88, c22);
     A[1] = expand_bits_r(w.y, m88, c22);
@@ -177,12 +182,12 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
           for (int m = 0; m < 4; m++) Dn = mfma_step(An[m], B[0][m], Dn);
         }
         if (b == (NB >= 2 ? NB - 2 : 0)) {
-          w = wn;
-          wn = tr[2 * (size_t)min(j + 64 + c, last)];
-          An[0] = expand_bits_r(w.x, m88, c22);
-          An[1] = expand_bits_r(w.y, m88, c22);
-          An[2] = expand_bits_r(w.z, m88, c22);
-          An[3] = expand_bits_r(w.w, m88, c22);
+          An[0] = expand_bits_r(wn.x, m88, c22);
+          An[1] = expand_bits_r(wn.y, m88, c22);
+          An[2] = expand_bits_r(wn.z, m88, c22);
+          An[3] = expand_bits_r(wn.w, m88, c22);
+          wn = row(off);
+          off += 1024u;
         }
         asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the minimum tree (and their result in VGPRs)
         int x[16];
@@ -191,11 +196,17 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
         const int m = group_min(x);
         second[b] = med3(best[b], m, second[b]);
         best[b] = min(best[b], m | (int)step16);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        // issue order of a step: each of the four MFMAs followed by three of the step's ~15 VALU
+        // instructions (tools/mfma_scan.hip -DVSM_PRODUCT: 2+4+1+4+1, 1+4 x 4, 1+2 x 4, 2+6 x 2 are
+        // all within the run-to-run noise of +-1.5 %; this one needs the fewest registers, 237)
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         D = Dn;
       }
 #pragma unroll
