@@ -1,65 +1,81 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 rocpd databases written by tools/profile_bench.sh into the
-text summaries committed under profiles/.  usage: summarize_prof.py <prof dir> <out dir>"""
+text summaries committed under profiles/ and into pmc_summary.json, which bench.py reads for
+roofline.traffic / sustained_clock_ghz / mfma_busy_frac.  usage: summarize_prof.py <prof dir> <out dir>"""
+import json
 import os
 import sqlite3
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+DOMINANT = "mfma_scan_kernel<8, 1>"
+XCDS, SIMDS = 8, 1024
 
 
 def q(db, sql):
     return sqlite3.connect(db).execute(sql).fetchall()
 
 
+cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py"
+line = json.loads(open(os.path.join(src, "trace.json")).readline())
+pairs = int(line["config"]["pairs_per_rank_per_step"])
+top = q(os.path.join(src, "trace", "t_results.db"), "select * from top_kernels")
 with open(os.path.join(dst, "kernel_trace_stats.txt"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-extra --cpu-pairs 0 --pairs 16384\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 {cmd}   ({pairs} pairs per launch, the bench default)\n")
     f.write("# columns: kernel | calls | total_us | avg_us | percent\n")
-    for name, calls, total, avg, pct in q(os.path.join(src, "trace", "t_results.db"), "select * from top_kernels"):
+    for name, calls, total, avg, pct in top:
         f.write(f"{name.split('(')[0]:60s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:8.3f}\n")
+    r = line["roofline"]
+    f.write(f"# the bench line of this same (profiled) run: avg_launch_ms {r['avg_launch_ms']:.3f} (HIP events), "
+            f"kernel {r['kernel_gcomps']:.0f} G comparisons/s, roofline.frac {r['frac']:.4f}\n")
 
 ex = os.path.join(src, "trace_extras", "t_results.db")
 if os.path.exists(ex):
     with open(os.path.join(dst, "kernel_trace_stats_extras.txt"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 1 --cpu-pairs 0 --pairs 4096\n")
-        f.write("# (with the extras: stereo pair, find_matches_landmarks frame, ORB frame, config-3 shape, dense overlap, 1M x 1M)\n")
+        f.write("# (with the extras: stereo pair, find_matches_landmarks frame, ORB frame, config-3 shape, dense overlap, real-like, 1M x 1M)\n")
         f.write("# columns: kernel | calls | total_us | avg_us | percent\n")
         for name, calls, total, avg, pct in q(ex, "select * from top_kernels"):
             f.write(f"{name.split('(')[0]:60s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:8.3f}\n")
 
+ctr = {}
 with open(os.path.join(dst, "pmc_counters.txt"), "w") as f:
-    f.write("# rocprofv3 --pmc <counters> (one run per group) -- same command; per-dispatch averages\n")
+    f.write(f"# rocprofv3 --pmc <counters> (one run per group) -- python3 {cmd}; per-dispatch averages\n")
     f.write("# columns: kernel | counter | dispatches | avg value per dispatch\n")
-    for d in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_mfma"):
+    for d in ("pmc_mfma", "pmc_sq", "pmc_fetch", "pmc_write"):
         p = os.path.join(src, d, "p_results.db")
         if not os.path.exists(p):
             continue
-        for name, ctr, n, avg in q(p, "select kernel_name, counter_name, count(*), avg(value) from counters_collection "
-                                      "group by kernel_name, counter_name order by kernel_name, counter_name"):
-            f.write(f"{name.split('(')[0]:50s} {ctr:22s} {n:4d} {avg:20.1f}\n")
-print(open(os.path.join(dst, "kernel_trace_stats.txt")).read())
-print(open(os.path.join(dst, "pmc_counters.txt")).read())
+        for name, c, n, avg in q(p, "select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+                                    "group by kernel_name, counter_name order by kernel_name, counter_name"):
+            f.write(f"{name.split('(')[0]:50s} {c:26s} {n:4d} {avg:20.1f}\n")
+            if DOMINANT in name:
+                ctr[(d, c)] = avg
 
-# HBM traffic of the dominant kernel per image pair, for bench.py's roofline.traffic
-import json
-vals = {}
-# the dominant kernel = the scan kernel with the largest summed FETCH_SIZE; WRITE_SIZE of the same kernel
-r = q(os.path.join(src, "pmc_fetch", "p_results.db"),
-      "select kernel_name, avg(value) from counters_collection where counter_name='FETCH_SIZE' and "
-      "kernel_name like '%scan_kernel%' group by kernel_name order by sum(value) desc")
-full_name, vals["FETCH_SIZE"] = r[0]
-kname = full_name.split("(")[0].replace("void vsm::", "")
-r = q(os.path.join(src, "pmc_write", "p_results.db"),
-      "select kernel_name, avg(value) from counters_collection where counter_name='WRITE_SIZE' group by kernel_name")
-vals["WRITE_SIZE"] = [v for n, v in r if n == full_name][0]
-pairs = 16384
-json.dump({"kernel": kname, "pairs_per_launch": pairs,
-           "FETCH_SIZE_KB_per_launch": vals["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": vals["WRITE_SIZE"],
-           "bytes_per_pair": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / pairs,
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_bench.sh); raw counter "
-                   "values in KiB. bytes_per_pair = (2 x FETCH_SIZE + WRITE_SIZE) / pairs: the x2 gfx950 correction of "
-                   "MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of 16 B/lane global loads) applies, the "
-                   "matrix-core scan reads every descriptor through global_load_dwordx4. WRITE_SIZE is exact "
-                   "(8 B per query)."},
-          open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+avg_us = [avg for name, calls, total, avg, pct in top if DOMINANT in name][0]
+s = {"kernel": DOMINANT, "command": cmd, "pairs_per_launch": pairs, "avg_launch_us_kernel_trace": avg_us,
+     "avg_launch_ms_hip_events_same_run": line["roofline"]["avg_launch_ms"]}
+if ("pmc_fetch", "FETCH_SIZE") in ctr and ("pmc_write", "WRITE_SIZE") in ctr:
+    s["FETCH_SIZE_KB_per_launch"] = ctr[("pmc_fetch", "FETCH_SIZE")]
+    s["WRITE_SIZE_KB_per_launch"] = ctr[("pmc_write", "WRITE_SIZE")]
+    s["hbm_bytes_per_pair"] = (2 * s["FETCH_SIZE_KB_per_launch"] + s["WRITE_SIZE_KB_per_launch"]) * 1024 / pairs
+g = ctr.get(("pmc_mfma", "GRBM_GUI_ACTIVE"))
+b = ctr.get(("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES"))
+if g and b:
+    s["GRBM_GUI_ACTIVE_per_launch"] = g
+    s["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = b
+    s["SQ_INSTS_MFMA_per_launch"] = ctr.get(("pmc_mfma", "SQ_INSTS_MFMA"))
+    s["sustained_clock_ghz"] = g / XCDS / (avg_us * 1e-6) / 1e9
+    s["mfma_busy_frac"] = (b / SIMDS) / (g / XCDS)
+v = ctr.get(("pmc_sq", "SQ_INSTS_VALU"))
+if v and s.get("SQ_INSTS_MFMA_per_launch"):
+    s["valu_instructions_per_mfma"] = v / s["SQ_INSTS_MFMA_per_launch"]
+s["note"] = ("rocprofv3 --pmc, one pass per counter group (tools/profile_bench.sh); raw FETCH_SIZE / WRITE_SIZE in KiB. "
+             "hbm_bytes_per_pair = (2 x FETCH_SIZE + WRITE_SIZE) / pairs: the x2 gfx950 correction of MI355X_MICROARCH.md "
+             "(FETCH_SIZE reports half the bytes of 16 B/lane global loads) applies, the scan reads every descriptor through "
+             "global_load_dwordx4; WRITE_SIZE is exact (8 B per query).  sustained_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / "
+             "kernel-trace duration; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).")
+json.dump(s, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print(open(os.path.join(dst, "kernel_trace_stats.txt")).read())
+print(json.dumps(s, indent=1))

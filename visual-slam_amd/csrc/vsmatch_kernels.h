@@ -625,6 +625,7 @@ __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
 // rows instead of every row's result.  Exact: every backward result the consumer kernels read is
 // computed.  Needs stride <= NOMINATE_MAX_STRIDE (LDS bitmap) and splits == 1.
 constexpr u32 NOMINATE_MAX_STRIDE = 65536;
+constexpr u32 NOMINATE_LDS_LIST = 2048;
 __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
                                                        uint2* __restrict__ scratch,
                                                        AcceptParams prm, u32 stride,
@@ -636,6 +637,10 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   __shared__ uint16_t lut[260];
   __shared__ u32 bitmap[NOMINATE_MAX_STRIDE / 32];
   __shared__ u32 wave_cnt[4];
+  // the first NOMINATE_LDS_LIST listed rows also stay in LDS between steps 1 and 2: reading them
+  // back from global memory right after writing them cost a round trip per workgroup (215 us per
+  // 32768 sparse pairs against 80 us)
+  __shared__ u32 slist[NOMINATE_LDS_LIST];
   load_lut(lut, prm);
   const u32 p = blockIdx.x;
   Job f = jobs[p];
@@ -675,8 +680,11 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
       u32 pos;
       acc = place((u32)__popc(bits), acc, pos);
       while (bits) {
-        list[pos++] = w * 32 + (u32)__builtin_ctz(bits);
+        const u32 i = w * 32 + (u32)__builtin_ctz(bits);
         bits &= bits - 1;
+        if (pos < NOMINATE_LDS_LIST) slist[pos] = i;
+        else list[pos] = i;
+        pos++;
       }
     }
   } else {
@@ -685,10 +693,13 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
       u32 j = 0, pos;
       const bool hit = i < f.nq && accepted(scratch[f.out_off + i], lut, prm.threshold, j);
       acc = place(hit ? 1u : 0u, acc, pos);
-      if (hit) list[pos] = i;
+      if (hit) {
+        if (pos < NOMINATE_LDS_LIST) slist[pos] = i;
+        else list[pos] = i;
+      }
     }
   }
-  __syncthreads();  // the list is read back below by other threads
+  __syncthreads();  // the list is read below by other threads
   // refine the listed rows, drop those that fail now (in place: a chunk writes at or below where
   // it read, after every thread has read), mark the columns of the others
   u32 kept = 0;
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
     u32 i = 0, j = 0;
     bool keep = false;
     if (k < acc) {
-      i = list[k];
+      i = k < NOMINATE_LDS_LIST ? slist[k] : list[k];
       uint2 v = scratch[f.out_off + i];
       j = v.x & IDX_MASK;
       keep = true;
@@ -715,12 +726,15 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   }
   __syncthreads();
   u32 done = 0;
-  for (u32 base = 0; base < n2; base += 256) {
-    const u32 j = base + threadIdx.x;
-    const bool hit = j < n2 && ((bitmap[j >> 5] >> (j & 31)) & 1u);
+  for (u32 base = 0; base < words; base += 256) {  // a thread takes a 32-column word of the bitmap
+    const u32 w = base + threadIdx.x;
+    u32 bits = w < words ? bitmap[w] : 0u;
     u32 pos;
-    done = place(hit ? 1u : 0u, done, pos);
-    if (hit) qlist[(size_t)p * stride + pos] = j;
+    done = place((u32)__popc(bits), done, pos);
+    while (bits) {
+      qlist[(size_t)p * stride + pos++] = w * 32 + (u32)__builtin_ctz(bits);
+      bits &= bits - 1;
+    }
   }
   if (threadIdx.x == 0) {
     f.pad1 = kept;

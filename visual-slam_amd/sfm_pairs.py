@@ -6,7 +6,7 @@ parallelises over pairs with ``tbb::parallel_for`` (1295); here the pair list
 is cut block-cyclically over ranks (one process per GPU), the descriptor
 database is replicated with ONE broadcast (RCCL over xGMI; ``backend="nccl"``
 is RCCL on ROCm) and there is no communication while matching.  The result
-lists are gathered to rank 0 afterwards (counts first, then the flat lists).
+lists are gathered to rank 0 afterwards (counts first, then the flat lists), device to device.
 
 The per-rank matcher is injected (`match_pairs_fn`) so that the sharding and
 gathering logic can be exercised on CPU with the gloo backend; the default is
@@ -32,7 +32,9 @@ def shard_indices(n_pairs: int, rank: int, world: int, block: int = BLOCK) -> np
 def broadcast_database(desc: np.ndarray | None, offsets: np.ndarray | None, device, group=None, src: int = 0):
     """Replicates (desc uint64[n,4], offsets uint32[n_img+1]) from `src` to every
     rank: one broadcast of sizes, one of offsets, one of the descriptors.
-    Returns (desc_tensor on `device` as int64[n,4], offsets ndarray)."""
+    Returns (desc_tensor on `device` as int64[n,4], offsets ndarray).  The tensor is complete
+    when this returns (the device is synchronised): the matcher's context runs on a stream of
+    its own, which does not wait for the collective's stream by itself (include/vsmatch.h)."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
@@ -48,53 +50,64 @@ def broadcast_database(desc: np.ndarray | None, offsets: np.ndarray | None, devi
         d_t.copy_(torch.from_numpy(np.ascontiguousarray(desc).view(np.int64)))
     dist.broadcast(off_t, src, group=group)
     dist.broadcast(d_t, src, group=group)
-    return d_t, off_t.cpu().numpy().astype(np.uint32)
+    off = off_t.cpu().numpy().astype(np.uint32)
+    if d_t.is_cuda:
+        torch.cuda.synchronize(d_t.device)
+    return d_t, off
 
 
-def gather_matches(local_idx: np.ndarray, local_offsets: np.ndarray, local_matches: np.ndarray,
-                   n_pairs: int, device, group=None, dst: int = 0):
+def gather_matches(local_counts, local_matches, n_pairs: int, group=None, dst: int = 0, block: int = BLOCK):
     """Gathers every rank's per-pair lists to `dst` in canonical pair order.
-    Returns (offsets uint64[n_pairs+1], matches int32[total,2]) on dst, None elsewhere."""
+
+    `local_counts` (int tensor [n_local]): matches per pair of this rank's share, in the order
+    of shard_indices(n_pairs, rank, world, block); `local_matches` (int32 tensor [total, 2]): its
+    lists back to back.  Both live where the collectives of `group` want them (the GPU for RCCL,
+    the CPU for gloo) and stay there: sizes are all-gathered, counts and lists are gathered padded
+    to the largest share, and `dst` scatters every list to its place with vectorised index
+    arithmetic (which pairs a rank owns follows from the partition, nothing but counts and lists
+    travels).  Returns (offsets int64[n_pairs+1], matches int32[total,2]) tensors on dst, None
+    elsewhere."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    counts = np.diff(local_offsets.astype(np.int64))
-    sizes = torch.tensor([len(local_idx), len(local_matches)], dtype=torch.int64, device=device)
+    device = local_matches.device
+    local_counts = local_counts.to(device=device, dtype=torch.int64)
+    local_matches = local_matches.to(dtype=torch.int32).reshape(-1, 2)
+    sizes = torch.tensor([local_counts.numel(), local_matches.shape[0]], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
-    all_sizes = [tuple(int(v) for v in s.cpu()) for s in all_sizes]
+    all_sizes = torch.stack(all_sizes).cpu().tolist()
+    for r in range(world):
+        want = len(shard_indices(n_pairs, r, world, block)) if n_pairs < (1 << 22) else None
+        assert want is None or all_sizes[r][0] == want, "a rank's share does not follow the block-cyclic partition"
     max_p = max(1, max(s[0] for s in all_sizes))
     max_m = max(1, max(s[1] for s in all_sizes))
-    # padded payloads: [pair indices | counts] and the flat match list
-    head = torch.zeros(2 * max_p, dtype=torch.int64, device=device)
-    head[: len(local_idx)] = torch.from_numpy(local_idx.astype(np.int64))
-    head[max_p: max_p + len(counts)] = torch.from_numpy(counts)
+    head = torch.zeros(max_p, dtype=torch.int64, device=device)
+    head[: local_counts.numel()] = local_counts
     body = torch.zeros((max_m, 2), dtype=torch.int32, device=device)
-    if len(local_matches):
-        body[: len(local_matches)] = torch.from_numpy(np.ascontiguousarray(local_matches, dtype=np.int32))
+    body[: local_matches.shape[0]] = local_matches
     heads = [torch.zeros_like(head) for _ in range(world)] if rank == dst else None
     bodies = [torch.zeros_like(body) for _ in range(world)] if rank == dst else None
     dist.gather(head, heads, dst=dst, group=group)
     dist.gather(body, bodies, dst=dst, group=group)
     if rank != dst:
         return None
-    cnt = np.zeros(n_pairs, dtype=np.int64)
-    where = {}
+    idx = [torch.from_numpy(shard_indices(n_pairs, r, world, block)).to(device) for r in range(world)]
+    cnt = torch.zeros(n_pairs, dtype=torch.int64, device=device)
+    for r in range(world):
+        cnt[idx[r]] = heads[r][: all_sizes[r][0]]
+    offsets = torch.zeros(n_pairs + 1, dtype=torch.int64, device=device)
+    offsets[1:] = torch.cumsum(cnt, 0)
+    out = torch.empty((int(offsets[-1]), 2), dtype=torch.int32, device=device)
     for r in range(world):
         p, m = all_sizes[r]
-        h = heads[r].cpu().numpy()
-        idx, c = h[:p], h[max_p: max_p + p]
-        cnt[idx] = c
-        starts = np.concatenate([[0], np.cumsum(c)])[:-1]
-        where[r] = (idx, starts, c, bodies[r].cpu().numpy()[:m])
-    offsets = np.zeros(n_pairs + 1, dtype=np.uint64)
-    offsets[1:] = np.cumsum(cnt)
-    out = np.empty((int(offsets[-1]), 2), dtype=np.int32)
-    for r in range(world):
-        idx, starts, c, body_r = where[r]
-        for k in range(len(idx)):
-            o = int(offsets[idx[k]])
-            out[o: o + c[k]] = body_r[starts[k]: starts[k] + c[k]]
+        if m == 0:
+            continue
+        c = heads[r][:p]
+        local_start = torch.cumsum(c, 0) - c
+        # match k of rank r, in local pair q: global row = offsets[idx[q]] + (k - local_start[q])
+        shift = torch.repeat_interleave(offsets[idx[r]] - local_start, c)
+        out[shift + torch.arange(m, device=device)] = bodies[r][:m]
     return offsets, out
 
 
@@ -123,10 +136,16 @@ def match_all_sharded(desc, offsets, pairs, threshold: int = 70, dist_2_best: fl
     if match_pairs_fn is None:
         import torch
         match_pairs_fn = _hip_match_pairs(torch.cuda.current_device())
+    import torch
     pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
     mine = shard_indices(len(pairs), rank, world, block)
     loc_off, loc_matches = match_pairs_fn(desc, offsets, pairs[mine], threshold, dist_2_best)
-    return gather_matches(mine, np.asarray(loc_off), np.asarray(loc_matches), len(pairs), device, group)
+    counts = torch.from_numpy(np.diff(np.asarray(loc_off).astype(np.int64))).to(device)
+    lists = torch.from_numpy(np.ascontiguousarray(loc_matches, dtype=np.int32).reshape(-1, 2)).to(device)
+    res = gather_matches(counts, lists, len(pairs), group, block=block)
+    if res is None:
+        return None
+    return res[0].cpu().numpy().astype(np.uint64), res[1].cpu().numpy()
 
 
 # ---- 1M x 1M style one-direction matching (BASELINE.json config 4) -------------------------
