@@ -14,12 +14,15 @@
 // fallback.  Re-entrant: one library context per calling thread, as the
 // tbb::parallel_for callers need (src/sfm.cpp:1295-1321, 1397-1423).
 //
-// The device is taken from the environment variable VSM_DEVICE (default 0).
+// The device is taken from the environment variable VSM_DEVICE (default 0).  matchDescriptorsBatch
+// uses every GPU listed in VSM_DEVICES (comma separated, e.g. "0,1,2,3,4,5,6,7") when it is set.
 #pragma once
 
+#include <algorithm>
 #include <bitset>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -55,6 +58,36 @@ inline vsm_ctx* thread_context() {
       throw std::runtime_error(std::string("visnav::matchDescriptors (GPU): ") + vsm_last_error());
   }
   return t.ctx;
+}
+
+// One context per GPU of VSM_DEVICES, created on first use, shared by the process.
+struct DevicePool {
+  std::vector<vsm_ctx*> ctxs;
+  std::mutex mu;
+  ~DevicePool() {
+    for (vsm_ctx* c : ctxs) vsm_destroy(c);
+  }
+};
+
+inline DevicePool& device_pool() {
+  static DevicePool pool;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* list = std::getenv("VSM_DEVICES");
+    if (!list || !*list) return;
+    thread_context();  // the layout probe
+    for (const char* p = list; *p;) {
+      char* end = nullptr;
+      const long dev = std::strtol(p, &end, 10);
+      if (end == p) break;
+      vsm_ctx* c = nullptr;
+      if (vsm_create(int(dev), &c) != VSM_OK)
+        throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (VSM_DEVICES): ") + vsm_last_error());
+      pool.ctxs.push_back(c);
+      p = *end == ',' ? end + 1 : end;
+    }
+  });
+  return pool;
 }
 
 }  // namespace vsm_detail
@@ -107,14 +140,25 @@ inline void matchDescriptorsBatch(const std::vector<const std::vector<std::bitse
     pairs[2 * k + 1] = uint32_t(b);
     cap += std::min(sets[a]->size(), sets[b]->size());
   }
-  vsm_ctx* ctx = vsm_detail::thread_context();
   std::vector<uint64_t> offs(ids_to_match.size() + 1);
   std::vector<std::pair<int, int>> all(cap ? cap : 1);
   size_t total = 0;
-  if (vsm_db_upload(ctx, flat.data(), offsets.data(), sets.size()) != VSM_OK ||
-      vsm_match_pairs(ctx, pairs.data(), ids_to_match.size(), threshold, dist_2_best, offs.data(),
-                      reinterpret_cast<int32_t*>(all.data()), all.size(), &total) != VSM_OK)
-    throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPU): ") + vsm_last_error());
+  vsm_detail::DevicePool& pool = vsm_detail::device_pool();
+  if (!pool.ctxs.empty()) {
+    // all the GPUs of VSM_DEVICES: database replicated device to device, pairs dealt in blocks, one
+    // host thread per GPU inside the library (vsm_match_pairs_multi); the pool serves one batch at a time
+    std::lock_guard<std::mutex> lk(pool.mu);
+    if (vsm_db_upload_multi(pool.ctxs.data(), pool.ctxs.size(), flat.data(), offsets.data(), sets.size()) != VSM_OK ||
+        vsm_match_pairs_multi(pool.ctxs.data(), pool.ctxs.size(), pairs.data(), ids_to_match.size(), threshold,
+                              dist_2_best, offs.data(), reinterpret_cast<int32_t*>(all.data()), all.size(), &total) != VSM_OK)
+      throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPUs of VSM_DEVICES): ") + vsm_last_error());
+  } else {
+    vsm_ctx* ctx = vsm_detail::thread_context();
+    if (vsm_db_upload(ctx, flat.data(), offsets.data(), sets.size()) != VSM_OK ||
+        vsm_match_pairs(ctx, pairs.data(), ids_to_match.size(), threshold, dist_2_best, offs.data(),
+                        reinterpret_cast<int32_t*>(all.data()), all.size(), &total) != VSM_OK)
+      throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPU): ") + vsm_last_error());
+  }
   for (size_t k = 0; k < ids_to_match.size(); k++)
     out[k].assign(all.begin() + offs[k], all.begin() + offs[k + 1]);
 }

@@ -151,6 +151,22 @@ int vsm_match_pairs_device(vsm_ctx* ctx, const void* d_pairs, size_t n_pairs, in
                            size_t cap_pairs, size_t* out_total);
 
 /*
+ * match_all on all the GPUs of a node from ONE process (src/sfm.cpp:1276-1321 is one C++ executable):
+ * `ctxs` lists one context per GPU (vsm_create(device k, ...); several contexts on one GPU work too).
+ * vsm_db_upload_multi puts the database on every context: host memory to the first, device to device
+ * (hipMemcpyPeer, xGMI within a node) to the others.  vsm_match_pairs_multi is vsm_match_pairs over
+ * all of them: blocks of 4096 consecutive pairs are dealt round-robin to the contexts (the partition
+ * of visual-slam_amd/sfm_pairs.py), one host thread per context matches its share on its GPU with
+ * no communication, and the lists are merged into the caller's buffers in canonical pair order.
+ * Same outputs and errors as vsm_match_pairs; the contexts are busy (locked) for the whole call.
+ */
+int vsm_db_upload_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint64_t* desc, const uint32_t* offsets,
+                        size_t n_img);
+int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pairs, size_t n_pairs,
+                          int threshold, double dist_2_best, uint64_t* out_offsets, int32_t* out_pairs,
+                          size_t cap_pairs, size_t* out_total);
+
+/*
  * Replaces visnav::find_matches_landmarks, include/visnav/vo_utils.h:95-187 (called on
  * every odometry frame, src/odometry.cpp:832 and 887; test/src/test_ex5.cpp:200, 248).
  * The reference's containers flattened by the caller (the C++ shim

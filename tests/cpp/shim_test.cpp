@@ -68,6 +68,9 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "FAIL: batch\n");
     return 1;
   }
-  std::printf("shim ok: %zu matches, 8 concurrent callers, batch of 4\n", want.size());
+  // (with VSM_DEVICES set the batch above ran through vsm_match_pairs_multi: the test runs this
+  // binary a second time with VSM_DEVICES=0,0 -- two contexts on the one GPU)
+  std::printf("shim ok: %zu matches, 8 concurrent callers, batch of 4%s\n", want.size(),
+              std::getenv("VSM_DEVICES") ? " over the contexts of VSM_DEVICES" : "");
   return 0;
 }

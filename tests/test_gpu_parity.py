@@ -310,9 +310,47 @@ def test_cpp_shim_reference_signature():
     exe = os.path.join(root, "cpp", "shim_test")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     g = cases.GOLDEN
-    r = subprocess.run([exe, os.path.join(g, "ex3_kd0.npy"), os.path.join(g, "ex3_kd1.npy"),
-                        os.path.join(g, "ex3_matches.npy")], capture_output=True, text=True, timeout=100)
-    assert r.returncode == 0, r.stdout + r.stderr
+    for devices in (None, "0,0"):  # one thread-local context; two contexts of vsm_match_pairs_multi on the one GPU
+        env = dict(os.environ)
+        env.pop("VSM_DEVICES", None)
+        if devices:
+            env["VSM_DEVICES"] = devices
+        r = subprocess.run([exe, os.path.join(g, "ex3_kd0.npy"), os.path.join(g, "ex3_kd1.npy"),
+                            os.path.join(g, "ex3_matches.npy")], capture_output=True, text=True, timeout=100, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("VSM_DEVICES" in r.stdout) == bool(devices)
+
+
+def test_multi_context_batch_equals_single_context(m):
+    """vsm_db_upload_multi / vsm_match_pairs_multi (match_all on several GPUs from one process,
+    src/sfm.cpp:1276-1321): two and three contexts on device 0 give the offsets and lists of the
+    single-context call, in the order of the pair list -- ragged database, more pairs than one
+    4096-pair block per context, both orientations, an empty image; capacity and bad-index errors
+    behave like vsm_match_pairs."""
+    rng = np.random.default_rng(17)
+    sizes = rng.integers(0, 500, size=150)
+    sizes[7] = 0
+    db, off = cases.synth.sfm_database(150, sizes, seed=23, share_frac=0.5, window=10)
+    pairs = cases.synth.all_pairs(150)
+    pairs = np.concatenate([pairs, pairs[::-1, ::-1]])  # 22350 pairs: 6 blocks
+    m.db_upload(db, off)
+    want_off, want = m.match_pairs(pairs, 70, 1.2)
+    assert len(want) > 20000
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        with vsm.MultiMatcher(devices) as mm:
+            mm.db_upload(db, off)
+            got_off, got = mm.match_pairs(pairs, 70, 1.2)
+            assert np.array_equal(got_off, want_off) and np.array_equal(got, want), devices
+            o2, l2 = mm.match_pairs(pairs[:5000], 90, 1.0)  # another batch on the same contexts
+            w2 = m.match_pairs(pairs[:5000], 90, 1.0)
+            assert np.array_equal(o2, w2[0]) and np.array_equal(l2, w2[1])
+            o3, l3 = mm.match_pairs(np.zeros((0, 2), np.uint32))
+            assert list(o3) == [0] and len(l3) == 0
+            with pytest.raises(vsm.VsmError) as e:
+                mm.match_pairs(pairs, 70, 1.2, cap=100)
+            assert e.value.code == vsm.matcher.VSM_ERR_CAPACITY
+            with pytest.raises(vsm.VsmError):
+                mm.match_pairs(np.array([[0, 999]], np.uint32), cap=10)
 
 
 def test_config3_shape_euroc_like_all_pairs(m):

@@ -10,4 +10,4 @@ The directory name has a hyphen, so import it with
 """
 from . import synth  # noqa: F401
 from . import matcher  # noqa: F401
-from .matcher import Matcher, VsmError, match_descriptors  # noqa: F401
+from .matcher import Matcher, MultiMatcher, VsmError, match_descriptors  # noqa: F401

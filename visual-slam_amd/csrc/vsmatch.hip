@@ -17,8 +17,11 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "vsmatch.h"
@@ -727,6 +730,162 @@ int vsm_match_pairs(vsm_ctx* c, const uint32_t* pairs, size_t n_pairs, int thres
   if (n_copy) HIP_TRY(hipMemcpyAsync(out_pairs, c->w_out.p, n_copy * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return rc;
+}
+
+int vsm_db_upload_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint64_t* desc, const uint32_t* offsets, size_t n_img) {
+  if (!ctxs || n_ctx == 0) return fail(VSM_ERR_INVALID, "no contexts");
+  for (size_t k = 0; k < n_ctx; k++) VSM_TRY(check_ctx(ctxs[k]));
+  VSM_TRY(vsm_db_upload(ctxs[0], desc, offsets, n_img));  // validates everything, host -> first context
+  vsm_ctx* c0 = ctxs[0];
+  const size_t bytes = (size_t)offsets[n_img] * DESC_BYTES;
+  for (size_t k = 1; k < n_ctx; k++) {
+    vsm_ctx* c = ctxs[k];
+    if (c == c0) continue;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    DeviceGuard g(c->device);
+    c->db = nullptr;
+    c->img_off.clear();
+    VSM_TRY(c->db_owned.reserve(std::max<size_t>(bytes, 256)));
+    if (bytes) {
+      // device to device: xGMI between the GPUs of a node (the runtime stages through the host where
+      // two devices are not peers); from the host again if that fails
+      hipError_t e = c->device == c0->device
+                         ? hipMemcpy(c->db_owned.p, c0->db_owned.p, bytes, hipMemcpyDeviceToDevice)
+                         : hipMemcpyPeer(c->db_owned.p, c->device, c0->db_owned.p, c0->device, bytes);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipMemcpy(c->db_owned.p, desc, bytes, hipMemcpyHostToDevice));
+      }
+    }
+    VSM_TRY(set_db(c, c->db_owned.p, offsets, n_img));
+  }
+  return VSM_OK;
+}
+
+int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pairs, size_t n_pairs, int threshold,
+                          double dist_2_best, uint64_t* out_offsets, int32_t* out_pairs, size_t cap_pairs,
+                          size_t* out_total) {
+  if (!ctxs || n_ctx == 0) return fail(VSM_ERR_INVALID, "no contexts");
+  if (!out_total || !out_offsets) return fail(VSM_ERR_INVALID, "null output pointer");
+  if (n_pairs && !pairs) return fail(VSM_ERR_INVALID, "null pairs pointer");
+  if (cap_pairs && !out_pairs) return fail(VSM_ERR_INVALID, "null out_pairs with non-zero capacity");
+  for (size_t k = 0; k < n_ctx; k++) {
+    VSM_TRY(check_ctx(ctxs[k]));
+    for (size_t l = 0; l < k; l++)
+      if (ctxs[l] == ctxs[k]) return fail(VSM_ERR_INVALID, "context %zu is listed twice", k);
+    if (ctxs[k]->img_off.empty()) return fail(VSM_ERR_INVALID, "context %zu has no database: call vsm_db_upload_multi first", k);
+  }
+  constexpr size_t BLOCK = 4096;  // consecutive pairs share an image: a block keeps it hot in the L2s
+  const size_t n_blocks = (n_pairs + BLOCK - 1) / BLOCK;
+  struct Part {
+    std::vector<uint32_t> pairs;
+    std::vector<u64> off;  // local offsets, n_local + 1
+    size_t total = 0, cap = 0;  // matches of this share; capacity its device buffer was filled up to
+    int rc = VSM_OK;
+    std::string err;
+  };
+  std::vector<Part> parts(n_ctx);
+  std::mutex bm;
+  std::condition_variable bcv;
+  size_t arrived = 0;
+  bool released = false;
+  u64 grand_total = 0;
+
+  auto worker = [&](size_t k) {
+    vsm_ctx* c = ctxs[k];
+    Part& pt = parts[k];
+    // phase 1: this context's blocks k, k + n_ctx, ... as one batch on its GPU, lists stay in its HBM
+    for (size_t b = k; b < n_blocks; b += n_ctx) {
+      const size_t p0 = b * BLOCK, p1 = std::min(n_pairs, p0 + BLOCK);
+      pt.pairs.insert(pt.pairs.end(), pairs + 2 * p0, pairs + 2 * p1);
+    }
+    const size_t n_local = pt.pairs.size() / 2;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);  // held to the end: the lists live in the context's buffers
+    DeviceGuard g(c->device);
+    auto run = [&]() -> int {
+      const size_t n_img = c->img_off.size() - 1;
+      size_t bound = 0;  // the cross-check emits at most min(n1, n2) pairs per image pair
+      for (size_t i = 0; i < n_local; i++) {
+        const uint32_t a = pt.pairs[2 * i], b = pt.pairs[2 * i + 1];
+        if (a < n_img && b < n_img)
+          bound += std::min(c->img_off[a + 1] - c->img_off[a], c->img_off[b + 1] - c->img_off[b]);
+      }
+      const size_t cap = pt.cap = std::min(cap_pairs, bound);
+      VSM_TRY(c->w_pairs.reserve(std::max<size_t>(n_local * 8, 8)));
+      VSM_TRY(c->w_offsets.reserve((n_local + 1) * 8));
+      VSM_TRY(c->w_out.reserve(std::max<size_t>(cap * 8, 8)));
+      if (n_local) HIP_TRY(hipMemcpyAsync(c->w_pairs.p, pt.pairs.data(), n_local * 8, hipMemcpyHostToDevice, c->stream));
+      const int rc = vsm_match_pairs_device(c, c->w_pairs.p, n_local, threshold, dist_2_best, c->w_offsets.p, c->w_out.p,
+                                            cap, &pt.total);
+      if (rc != VSM_OK && rc != VSM_ERR_CAPACITY) return rc;
+      pt.off.resize(n_local + 1);
+      HIP_TRY(hipMemcpyAsync(pt.off.data(), c->w_offsets.p, (n_local + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return rc;
+    };
+    pt.rc = run();
+    if (pt.rc != VSM_OK) pt.err = g_err;
+    // barrier; the last context to arrive lays out the merged list in canonical pair order
+    {
+      std::unique_lock<std::mutex> bl(bm);
+      if (++arrived == n_ctx) {
+        bool ok = true;
+        for (const Part& q : parts) ok = ok && (q.rc == VSM_OK || q.rc == VSM_ERR_CAPACITY);
+        if (ok) {
+          u64 run_total = 0;
+          for (size_t b = 0; b < n_blocks; b++) {
+            const Part& q = parts[b % n_ctx];
+            const size_t p0 = b * BLOCK, p1 = std::min(n_pairs, p0 + BLOCK), l0 = (b / n_ctx) * BLOCK;
+            for (size_t p = p0; p < p1; p++) {
+              out_offsets[p] = run_total;
+              run_total += q.off[l0 + (p - p0) + 1] - q.off[l0 + (p - p0)];
+            }
+          }
+          out_offsets[n_pairs] = run_total;
+          grand_total = run_total;
+        }
+        released = true;
+        bcv.notify_all();
+      } else {
+        bcv.wait(bl, [&] { return released; });
+      }
+    }
+    for (const Part& q : parts)
+      if (q.rc != VSM_OK && q.rc != VSM_ERR_CAPACITY) return;
+    // phase 2: every block of this context is contiguous here and in the merged list
+    auto copy_out = [&]() -> int {
+      for (size_t b = k; b < n_blocks; b += n_ctx) {
+        const size_t p0 = b * BLOCK, p1 = std::min(n_pairs, p0 + BLOCK), l0 = (b / n_ctx) * BLOCK;
+        const u64 src0 = pt.off[l0], n = pt.off[l0 + (p1 - p0)] - src0, dst0 = out_offsets[p0];
+        // what the context's buffer holds (it was filled up to its own capacity) and what the caller's takes
+        const u64 have = src0 < pt.cap ? std::min<u64>(n, pt.cap - src0) : 0;
+        const u64 take = dst0 < cap_pairs ? std::min<u64>(have, cap_pairs - dst0) : 0;
+        if (take)
+          HIP_TRY(hipMemcpyAsync(out_pairs + 2 * dst0, (const char*)c->w_out.p + src0 * 8, take * 8, hipMemcpyDeviceToHost, c->stream));
+      }
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return VSM_OK;
+    };
+    const int rc2 = copy_out();
+    if (rc2 != VSM_OK) {
+      pt.rc = rc2;
+      pt.err = g_err;
+    }
+  };
+
+  if (n_ctx == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < n_ctx; k++) th.emplace_back(worker, k);
+    for (std::thread& t : th) t.join();
+  }
+  for (const Part& q : parts)
+    if (q.rc != VSM_OK && q.rc != VSM_ERR_CAPACITY) return fail(q.rc, "%s", q.err.c_str());
+  *out_total = (size_t)grand_total;
+  if (grand_total > cap_pairs)
+    return fail(VSM_ERR_CAPACITY, "%llu matches need more than cap_pairs=%zu", (unsigned long long)grand_total, cap_pairs);
+  return VSM_OK;
 }
 
 int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2, size_t n2,

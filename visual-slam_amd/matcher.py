@@ -25,7 +25,7 @@ VSM_MAX_SET = 1 << 23
 SYMBOLS = (
     "vsm_version", "vsm_last_error", "vsm_create", "vsm_destroy", "vsm_stream",
     "vsm_match_pair", "vsm_match_pair_noalloc", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
-    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
+    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_db_upload_multi", "vsm_match_pairs_multi", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
     "vsm_set_profiling",
     "vsm_set_variant", "vsm_accept_limit",
     "vsm_match_landmarks",
@@ -70,6 +70,9 @@ def lib():
             L.vsm_db_attach.argtypes = [_vp, _vp, _vp, _sz]
             L.vsm_match_pairs.argtypes = [_vp, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz, C.POINTER(_sz)]
             L.vsm_match_pairs_device.argtypes = [_vp, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz, C.POINTER(_sz)]
+            L.vsm_db_upload_multi.argtypes = [C.POINTER(_vp), _sz, _vp, _vp, _sz]
+            L.vsm_match_pairs_multi.argtypes = [C.POINTER(_vp), _sz, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz,
+                                                C.POINTER(_sz)]
             L.vsm_last_scan_stats.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_last_scan_stats_kind.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
@@ -370,6 +373,52 @@ class Matcher:
         else:
             _check(lib().vsm_last_scan_stats_kind(self._h, int(kind), C.byref(ms), C.byref(n), C.byref(comps)))
         return {"scan_ms": ms.value, "launches": n.value, "comparisons": comps.value}
+
+
+class MultiMatcher:
+    """match_all over several contexts from one process (vsm_db_upload_multi / vsm_match_pairs_multi):
+    one context per entry of `devices` (a device may be listed more than once)."""
+
+    def __init__(self, devices):
+        self.matchers = [Matcher(d) for d in devices]
+        self._arr = (_vp * len(self.matchers))(*[m._h for m in self.matchers])
+        self._offsets = None
+
+    def close(self):
+        for m in self.matchers:
+            m.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def db_upload(self, desc, offsets):
+        desc = as_descriptors(desc)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        if offsets.ndim != 1 or len(offsets) < 1 or int(offsets[-1]) != len(desc):
+            raise ValueError("offsets must be uint32[n_img+1] ending at len(desc)")
+        _check(lib().vsm_db_upload_multi(self._arr, len(self.matchers), _ptr(desc), _ptr(offsets), len(offsets) - 1))
+        self._offsets = offsets
+
+    def match_pairs(self, pairs, threshold: int = 70, dist_2_best: float = 1.2, cap: int | None = None):
+        """-> (offsets uint64[n+1], matches int32[total, 2]) in the order of `pairs`."""
+        if self._offsets is None:
+            raise VsmError(VSM_ERR_INVALID, "no database uploaded")
+        pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+        n = len(pairs)
+        if cap is None:
+            sizes = np.diff(self._offsets.astype(np.int64))
+            ok = (pairs < len(sizes)).all(axis=1) if n else np.zeros(0, bool)
+            cap = int(np.minimum(sizes[pairs[ok, 0]], sizes[pairs[ok, 1]]).sum()) if n else 0
+        cap = max(int(cap), 1)
+        offs = np.empty(n + 1, dtype=np.uint64)
+        out = np.empty((cap, 2), dtype=np.int32)
+        total = _sz(0)
+        _check(lib().vsm_match_pairs_multi(self._arr, len(self.matchers), _ptr(pairs), n, int(threshold), float(dist_2_best),
+                                           _ptr(offs), _ptr(out), cap, C.byref(total)))
+        return offs, out[: total.value].copy()
 
 
 def bow_vector(words, weights):
