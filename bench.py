@@ -468,7 +468,8 @@ def main():
         m.set_profiling(False)
         extra["stereo_1500x1500"] = {"latency_ms_host_to_host": lat * 1e3, "scan_kernel_ms": scan_only,
                                      "matches": int(len(res)), "reference_equivalent_gcomps": 2 * 1500 * 1500 / lat / 1e9,
-                                     "note": "host pointers in, host list out: H2D + 3 kernels (scan, merge, emit) + D2H, PCIe inclusive"}
+                                     "note": "host pointers in, host list out, PCIe inclusive: 4 kernels in one queue (staging from mapped host memory, "
+                                             "scan, merge + refine, emit into mapped host memory), the host polls a flag"}
         # next row N1: one odometry frame of find_matches_landmarks
         # (vo_utils.h:95-187, odometry.cpp:832): 1500 keypoints x 2500 projected landmarks,
         # radius 20 px (odometry.cpp:177), host pointers in/out; CPU = the C oracle, 1 thread
@@ -492,7 +493,8 @@ def main():
             "latency_ms_host_to_host": llat * 1e3, "scan_kernel_ms": lscan, "matches": int(len(lres)),
             "cpu_port_ms_1_thread": lcpu * 1e3, "bit_exact_vs_cpu": bool(np.array_equal(lres, lwant)),
             "observations": int(lf[3][-1]),
-            "note": "H2D + 3 kernels + D2H, PCIe inclusive; the gate evaluates 3.75 M point pairs in double"}
+            "note": "4 kernels in one queue (staging from mapped host memory, scan, merge, emit into mapped host memory), PCIe "
+                    "inclusive; the gate evaluates 3.75 M point pairs in double"}
         # next row N2: computeAngles + computeDescriptors (keypoints.h:151-237) for
         # one 752 x 480 EuRoC-sized frame with 1500 corners; host image in, host descriptors out
         rng = np.random.default_rng(a.seed)

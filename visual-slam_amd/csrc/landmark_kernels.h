@@ -88,15 +88,18 @@ __global__ __launch_bounds__(256) void landmark_scan_kernel(
 // out[0..1] (as u64) = number of matches; pairs follow at out_pairs.  A keypoint with no
 // candidate (index -1 in the reference, where reading projected_track_ids[-1] is undefined
 // behaviour) is never emitted.
-__global__ __launch_bounds__(256) void landmark_emit_kernel(const uint2* __restrict__ scratch, u32 nk,
-                                                            AcceptParams prm, u64* __restrict__ out_count,
-                                                            int2* __restrict__ out_pairs, u64 cap_pairs) {
+// Any workgroup size up to 1024.  `flag` (may be null): raised with system scope after everything
+// else has been written (the outputs may live in mapped host memory), for a host that polls.
+__global__ __launch_bounds__(1024) void landmark_emit_kernel(const uint2* __restrict__ scratch, u32 nk,
+                                                             AcceptParams prm, u64* __restrict__ out_count,
+                                                             int2* __restrict__ out_pairs, u64 cap_pairs,
+                                                             u64* __restrict__ flag, u64 seq) {
   __shared__ uint16_t lut[260];
-  __shared__ u32 wave_cnt[4];
+  __shared__ u32 wave_cnt[16];
   load_lut(lut, prm);
-  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   u32 done = 0;
-  for (u32 base = 0; base < nk; base += 256) {
+  for (u32 base = 0; base < nk; base += blockDim.x) {
     const u32 i = base + threadIdx.x;
     u32 j = 0;
     const bool hit = i < nk && accepted(scratch[i], lut, prm.threshold, j);
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void landmark_emit_kernel(const uint2* __restr
     if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
     __syncthreads();
     u32 before = done, all = 0;
-    for (u32 w = 0; w < 4; w++) {
+    for (u32 w = 0; w < n_waves; w++) {
       if (w < wave) before += wave_cnt[w];
       all += wave_cnt[w];
     }
@@ -116,6 +119,11 @@ __global__ __launch_bounds__(256) void landmark_emit_kernel(const uint2* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) *out_count = done;
+  if (flag) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 }  // namespace vsm

@@ -11,6 +11,7 @@
 #include "bow_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
 #include <cstdarg>
@@ -86,22 +87,28 @@ struct DevBuf {
 
 struct PinBuf {
   void* p = nullptr;
+  void* dev = nullptr;  // the same memory as the device sees it (mapped buffers only)
   size_t cap = 0;
+  unsigned flags = hipHostMallocDefault;
   int reserve(size_t bytes) {
     if (bytes <= cap) return VSM_OK;
     if (p) {
       HIP_TRY(hipHostFree(p));
-      p = nullptr;
+      p = dev = nullptr;
       cap = 0;
     }
     size_t want = std::max(bytes + bytes / 4, (size_t)4096);
-    HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&p, want, flags));
     cap = want;
+    if (flags != hipHostMallocDefault && hipHostGetDevicePointer(&dev, p, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      dev = nullptr;
+    }
     return VSM_OK;
   }
   void release() {
     if (p) (void)hipHostFree(p);
-    p = nullptr;
+    p = dev = nullptr;
     cap = 0;
   }
 };
@@ -145,6 +152,10 @@ struct vsm_ctx {
   DevBuf voc;          // vocabulary tree (vsm_voc_upload)
   size_t voc_nodes = 0, voc_off[6] = {0, 0, 0, 0, 0, 0};
   PinBuf pin, pin_image;
+  // vsm_match_pair's results: host memory the emit kernel writes directly (mapped, coherent), so the
+  // call needs no device-to-host copy and can poll a flag instead of waiting on the stream
+  PinBuf pin_out, pin_in;  // pin_in: its inputs, read by stage_in_kernel (mapped)
+  u64 pair_seq = 0;
   void* noalloc = nullptr;  // this device's copy of g_noalloc_scratch (hipGetSymbolAddress in vsm_create)
   // measurement
   bool profiling = false;
@@ -174,13 +185,17 @@ struct DeviceGuard {
 void make_accept(int threshold, double dist_2_best, AcceptParams* prm) {
   prm->threshold = threshold;
   for (int b = 0; b <= 256; b++) {
+    // min_second[b] = smallest s in 0..256 with `dist_2_best * b <= s` as keypoints.h:296 evaluates it
+    // (both sides double), 257 if there is none.  x is ONE double; the predicate is monotone in s, so
+    // the answer is ceil(x) clamped -- confirmed with the predicate itself, so that no rounding
+    // argument is needed (a 257 x 257 search of the predicate cost 13 us per call).
+    const double x = dist_2_best * b;
     int need = 257;
-    for (int s = 0; s <= 256; s++) {
-      // keypoints.h:296, evaluated in double exactly as the reference does
-      if (dist_2_best * b <= s) {
-        need = s;
-        break;
-      }
+    if (x <= 0.0) need = 0;               // also -inf, -0.0
+    else if (x <= 256.0) {                // NaN and everything above 256 fail both tests: 257
+      need = (int)std::ceil(x);
+      while (need > 0 && x <= (double)(need - 1)) need--;
+      while (need <= 256 && !(x <= (double)need)) need++;
     }
     prm->min_second[b] = (uint16_t)need;
   }
@@ -595,6 +610,8 @@ int vsm_create(int device, vsm_ctx** out) {
   vsm_ctx* c = new (std::nothrow) vsm_ctx;
   if (!c) return fail(VSM_ERR_NOMEM, "out of host memory");
   c->device = device;
+  c->pin_out.flags = hipHostMallocMapped | hipHostMallocCoherent;
+  c->pin_in.flags = hipHostMallocMapped | hipHostMallocCoherent;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     delete c;
@@ -622,6 +639,8 @@ void vsm_destroy(vsm_ctx* c) {
       b->release();
     c->pin.release();
     c->pin_image.release();
+    c->pin_out.release();
+    c->pin_in.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -904,14 +923,21 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   AcceptParams prm;
   make_accept(threshold, dist_2_best, &prm);
 
-  // One pinned staging block: [d1 | d2 | Job f | Job b] up, [offsets(2 x u64) | pairs] down.
+  // Latency path (one call per odometry keyframe): everything stays in the compute queue.
+  // Up: [d1 | d2 | Job f | Job b] in mapped host memory, copied to HBM by stage_in_kernel (an SDMA
+  // copy in front of the kernels cost ~14 us of cross-engine waiting).  Down: the emit kernel writes
+  // [offsets (2 x u64) | flag, pad to 64 | pairs] straight into mapped host memory and raises the
+  // flag last; the host polls it (a device-to-host copy + stream wait cost ~8 us).  With the 13 us
+  // the accept table used to take: 57 -> 28 us per 1500 x 1500 call from C.
   const size_t nmin = std::min(n1, n2);
   const size_t up_bytes = (n1 + n2) * DESC_BYTES + 2 * sizeof(Job);
-  const size_t down_bytes = 16 + nmin * 8;
-  VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
-  VSM_TRY(c->stage.reserve(up_bytes));
-  VSM_TRY(c->w_out.reserve(down_bytes));
-  char* h = (char*)c->pin.p;
+  const size_t down_bytes = 64 + nmin * 8;
+  VSM_TRY(c->pin_in.reserve(up_bytes + 16));
+  VSM_TRY(c->pin_out.reserve(down_bytes));
+  VSM_TRY(c->stage.reserve(up_bytes + 16));
+  const bool mapped = c->pin_out.dev != nullptr;
+  if (!mapped) VSM_TRY(c->w_out.reserve(down_bytes));
+  char* h = (char*)c->pin_in.p;
   memcpy(h, d1, n1 * DESC_BYTES);
   memcpy(h + n1 * DESC_BYTES, d2, n2 * DESC_BYTES);
   const u32 stride = std::max(64u, round_up((u32)std::max(n1, n2), 64));
@@ -919,7 +945,13 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   Job jb = {(u32)n1, (u32)n2, 0, (u32)n1, stride, NO_QLIST, 0, 0};
   memcpy(h + (n1 + n2) * DESC_BYTES, &jf, sizeof jf);
   memcpy(h + (n1 + n2) * DESC_BYTES + sizeof jf, &jb, sizeof jb);
-  HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+  if (c->pin_in.dev) {
+    const u32 n16 = (u32)((up_bytes + 15) / 16);
+    hipLaunchKernelGGL(stage_in_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->stream, (const u32x4*)c->pin_in.dev,
+                       (u32x4*)c->stage.p, n16);
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+  }
   const Job* d_jobs = (const Job*)((char*)c->stage.p + (n1 + n2) * DESC_BYTES);
 
   const ScanShape sh = choose_shape(2, (u32)std::max(n1, n2), (u32)std::max(n1, n2), c->variant);
@@ -927,25 +959,38 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   VSM_TRY(c->scratch.reserve((size_t)split_stride * sh.splits * sizeof(uint2)));
   VSM_TRY(launch_scan(c, c->stage.p, c->stage.p, d_jobs, 2, sh, split_stride, (uint2*)c->scratch.p,
                       2ull * n1 * n2, nullptr, accept_limit(prm)));
-  u64* d_off = (u64*)c->w_out.p;
-  int2* d_out = (int2*)((char*)c->w_out.p + 16);
+  char* d_down = mapped ? (char*)c->pin_out.dev : (char*)c->w_out.p;
+  volatile u64* h_flag = (volatile u64*)((char*)c->pin_out.p + 16);
+  const u64 seq = ++c->pair_seq;
   if (sh.splits > 1 || sh.mfma)
-    hipLaunchKernelGGL(merge_refine_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream, d_jobs, 1u,
+    hipLaunchKernelGGL(merge_refine_wide_kernel, dim3((split_stride + 15) / 16), dim3(256), 0, c->stream, d_jobs,
                        stride, (uint2*)c->scratch.p, sh.splits, split_stride, (const u32x4*)c->stage.p,
                        (const u32x4*)c->stage.p, prm, sh.mfma ? 1u : 0u);
-  hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(256), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
-                     split_stride, prm, d_off, d_out, (u64)nmin, 1u);
+  hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(1024), 0, c->stream, d_jobs, (const uint2*)c->scratch.p,
+                     split_stride, prm, (u64*)d_down, (int2*)(d_down + 64), (u64)nmin, 1u,
+                     mapped ? (u64*)(d_down + 16) : (u64*)nullptr, seq);
   HIP_TRY(hipGetLastError());
-  char* hd = h + up_bytes;
-  HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  char* hd = (char*)c->pin_out.p;
+  bool seen = false;
+  if (mapped && !c->profiling) {
+    // poll the flag the emit kernel raises after its last write (~2 s, then fall back to the stream)
+    for (u32 spin = 0; spin < (1u << 28) && !seen; spin++) {
+      seen = *h_flag == seq;
+      if (!seen) __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!seen) {
+    if (!mapped) HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (c->profiling) VSM_TRY(stats_collect(c));
   u64 offs[2];
   memcpy(offs, hd, 16);
   const size_t count = (size_t)offs[1];
   *out_count = count;
   if (count > cap_pairs) return fail(VSM_ERR_CAPACITY, "%zu matches need more than cap_pairs=%zu", count, cap_pairs);
-  if (count) memcpy(out_pairs, hd + 16, count * 8);
+  if (count) memcpy(out_pairs, hd + 64, count * 8);
   return VSM_OK;
 }
 
@@ -994,7 +1039,7 @@ int vsm_match_pair_noalloc(vsm_ctx* c, const void* d_d1, size_t n1, const void* 
                        1u, stride, d_scratch, sh.splits, split_stride, (const u32x4*)d_d1, (const u32x4*)d_d2, prm,
                        sh.mfma ? 1u : 0u);
   hipLaunchKernelGGL(pair_emit_kernel, dim3(1), dim3(256), 0, c->stream, (const Job*)d_jobs, (const uint2*)d_scratch,
-                     split_stride, prm, (u64*)d_out_count, (int2*)d_out_pairs, (u64)cap_pairs, 0u);
+                     split_stride, prm, (u64*)d_out_count, (int2*)d_out_pairs, (u64)cap_pairs, 0u, (u64*)nullptr, (u64)0);
   HIP_TRY(hipGetLastError());
   return VSM_OK;
 }
@@ -1088,17 +1133,27 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   const size_t o_kd = 0, o_od = o_kd + nk * DESC_BYTES, o_kx = o_od + al(std::max<size_t>(n_obs, 1) * DESC_BYTES);
   const size_t o_px = o_kx + al(nk * 16), o_of = o_px + al(np * 16), up_bytes = o_of + al((np + 1) * 4);
   const size_t cap = std::min(cap_pairs, nk);
-  const size_t down_bytes = 16 + nk * 8;
-  VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
-  VSM_TRY(c->stage.reserve(up_bytes));
-  VSM_TRY(c->w_out.reserve(down_bytes));
-  char* h = (char*)c->pin.p;
+  // (the latency path of vsm_match_pair: inputs staged by a kernel from mapped host memory, results
+  // written straight into mapped host memory with a flag the host polls)
+  const size_t down_bytes = 64 + nk * 8;  // [count u64 | flag u64 at 16 | pad to 64 | pairs]
+  VSM_TRY(c->pin_in.reserve(up_bytes + 16));
+  VSM_TRY(c->pin_out.reserve(down_bytes));
+  VSM_TRY(c->stage.reserve(up_bytes + 16));
+  const bool mapped = c->pin_out.dev != nullptr;
+  if (!mapped) VSM_TRY(c->w_out.reserve(down_bytes));
+  char* h = (char*)c->pin_in.p;
   memcpy(h + o_kd, kp_desc, nk * DESC_BYTES);
   if (n_obs) memcpy(h + o_od, obs_desc, n_obs * DESC_BYTES);
   memcpy(h + o_kx, kp_xy, nk * 16);
   memcpy(h + o_px, proj_xy, np * 16);
   memcpy(h + o_of, obs_off, (np + 1) * 4);
-  HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+  if (c->pin_in.dev) {
+    const u32 n16 = (u32)((up_bytes + 15) / 16);
+    hipLaunchKernelGGL(stage_in_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->stream, (const u32x4*)c->pin_in.dev,
+                       (u32x4*)c->stage.p, n16);
+  } else {
+    HIP_TRY(hipMemcpyAsync(c->stage.p, h, up_bytes, hipMemcpyHostToDevice, c->stream));
+  }
   char* d = (char*)c->stage.p;
 
   // Latency-bound: spread the projected points over enough waves to cover the chip
@@ -1123,18 +1178,32 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   c->scan_launches[0]++;
   hipLaunchKernelGGL(merge_splits_kernel, dim3((split_stride + 255) / 256), dim3(256), 0, c->stream,
                      (uint2*)c->scratch.p, split_stride, splits, split_stride);
-  hipLaunchKernelGGL(landmark_emit_kernel, dim3(1), dim3(256), 0, c->stream, (const uint2*)c->scratch.p,
-                     (u32)nk, prm, (u64*)c->w_out.p, (int2*)((char*)c->w_out.p + 16), (u64)cap);
+  char* d_down = mapped ? (char*)c->pin_out.dev : (char*)c->w_out.p;
+  const u64 seq = ++c->pair_seq;
+  hipLaunchKernelGGL(landmark_emit_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint2*)c->scratch.p,
+                     (u32)nk, prm, (u64*)d_down, (int2*)(d_down + 64), (u64)cap,
+                     mapped ? (u64*)(d_down + 16) : (u64*)nullptr, seq);
   HIP_TRY(hipGetLastError());
-  char* hd = h + up_bytes;
-  HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, 16 + cap * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  char* hd = (char*)c->pin_out.p;
+  volatile u64* h_flag = (volatile u64*)(hd + 16);
+  bool seen = false;
+  if (mapped && !c->profiling) {
+    for (u32 spin = 0; spin < (1u << 28) && !seen; spin++) {
+      seen = *h_flag == seq;
+      if (!seen) __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!seen) {
+    if (!mapped) HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, 64 + cap * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (c->profiling) VSM_TRY(stats_collect(c));
   u64 count;
   memcpy(&count, hd, 8);
   *out_count = (size_t)count;
   if (count > cap_pairs) return fail(VSM_ERR_CAPACITY, "%llu matches need more than cap_pairs=%zu", (unsigned long long)count, cap_pairs);
-  if (count) memcpy(out_pairs, hd + 16, count * 8);
+  if (count) memcpy(out_pairs, hd + 64, count * 8);
   return VSM_OK;
 }
 

@@ -536,21 +536,75 @@ __global__ __launch_bounds__(256) void fill_kernel(const Job* __restrict__ jobs,
   }
 }
 
+// The single-pair form of merge_refine_kernel (one stereo pair is latency bound: 3072 entries x 23
+// splits gave the one-thread-per-entry kernel 12 workgroups and ten dependent microseconds).  Sixteen
+// lanes per entry: lane l folds splits l, l + 16, ..., a 16-lane butterfly of merge2 (associative and
+// commutative) gives every lane the merged result, and if it passes the accept test each lane
+// takes ONE of the best's sixteen group rows (see refine_second) and a 16-lane minimum makes the
+// second best exact.  Lane 0 writes split 0.
+__global__ __launch_bounds__(256) void merge_refine_wide_kernel(const Job* __restrict__ jobs, u32 stride,
+                                                                uint2* __restrict__ scratch, u32 splits, u32 split_stride,
+                                                                const u32x4* __restrict__ desc_1,
+                                                                const u32x4* __restrict__ desc_2, AcceptParams prm,
+                                                                u32 refine) {
+  __shared__ uint16_t lut[260];
+  load_lut(lut, prm);
+  const u32 e = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  const u32 dir = e >= stride ? 1u : 0u, q = e - dir * stride;
+  const Job job = jobs[min(dir, 1u)];
+  const bool live = e < 2 * stride && q < job.nq;  // (whole 16-lane groups agree)
+  uint2 v = make_uint2(0xffffffffu, 0xffffffffu);
+  if (live)
+    for (u32 s = l; s < splits; s += 16) {
+      const uint2 w = scratch[(size_t)s * split_stride + e];
+      v = s == l ? w : merge2(v, w);
+    }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    const uint2 w = make_uint2((u32)__shfl_xor((int)v.x, o, 16), (u32)__shfl_xor((int)v.y, o, 16));
+    v = merge2(v, w);
+  }
+  u32 idx;
+  if (live && refine && accepted(v, lut, prm.threshold, idx)) {
+    const u32 d = v.x >> IDX_BITS;
+    u32 s2 = min(v.y >> IDX_BITS, 256u);
+    if (s2 > d) {  // uniform over the 16 lanes
+      const u32 per = (job.nt + splits - 1) / splits;
+      const u32 t0 = idx / per * per, t1 = min(t0 + per, job.nt);
+      const u32 r = t0 + ((idx - t0) & ~31u) + ((idx - t0) & 4u) + (l & 3u) + 8u * (l >> 2);
+      const u32x4* dq = (dir ? desc_2 : desc_1) + 2 * (size_t)(job.q_off + q);
+      const u32x4* dt = (dir ? desc_1 : desc_2) + 2 * ((size_t)job.t_off + min(r, t1 - 1));
+      const u32x4 qa = dq[0], qb = dq[1], ta = dt[0], tb = dt[1];
+      u32 dr = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+               __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+      dr = (r < t1 && r != idx) ? dr : 0x1ffu;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) dr = min(dr, (u32)__shfl_xor((int)dr, o, 16));
+      v.y = min(s2, dr) << IDX_BITS;
+    }
+  }
+  if (live && l == 0) scratch[e] = v;
+}
+
 // Single pair (vsm_match_pair, the odometry / match_stereo call): accept test, cross-check and
 // ordered emission in ONE single-workgroup kernel instead of count + scan_counts + fill (three
 // launches, ~22 us of a ~80 us call).  out_count[count_slot] = number of matches; pairs from out_pairs[0].
 // jobs[0] = forward job, jobs[1] = backward job; scratch holds the merged results (splits folded).
-__global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ jobs,
-                                                        const uint2* __restrict__ scratch, u32 split_stride,
-                                                        AcceptParams prm, u64* __restrict__ out_count,
-                                                        int2* __restrict__ out_pairs, u64 cap_pairs, u32 count_slot) {
+// Any workgroup size up to 1024.  `flag` (may be null): after everything else has been written --
+// the outputs may live in mapped host memory -- *flag = seq with system scope, for a host that
+// polls instead of waiting on the stream.
+__global__ __launch_bounds__(1024) void pair_emit_kernel(const Job* __restrict__ jobs,
+                                                         const uint2* __restrict__ scratch, u32 split_stride,
+                                                         AcceptParams prm, u64* __restrict__ out_count,
+                                                         int2* __restrict__ out_pairs, u64 cap_pairs, u32 count_slot,
+                                                         u64* __restrict__ flag, u64 seq) {
   __shared__ uint16_t lut[260];
-  __shared__ u32 wave_cnt[4];
+  __shared__ u32 wave_cnt[16];
   load_lut(lut, prm);
   const Job f = jobs[0], b = jobs[1];
-  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   u32 done = 0;
-  for (u32 base = 0; base < f.nq; base += 256) {
+  for (u32 base = 0; base < f.nq; base += blockDim.x) {
     const u32 i = base + threadIdx.x;
     u32 j = 0;
     const bool hit = cross_check(scratch, f, b, i, 1u, split_stride, lut, prm.threshold, j);
@@ -558,7 +612,7 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ 
     if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
     __syncthreads();
     u32 before = done, all = 0;
-    for (u32 w = 0; w < 4; w++) {
+    for (u32 w = 0; w < n_waves; w++) {
       if (w < wave) before += wave_cnt[w];
       all += wave_cnt[w];
     }
@@ -574,6 +628,19 @@ __global__ __launch_bounds__(256) void pair_emit_kernel(const Job* __restrict__ 
     if (count_slot) out_count[0] = 0;
     out_count[count_slot] = done;
   }
+  if (flag) {
+    __threadfence_system();  // this thread's pairs (and the count) before the flag, as the host sees them
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Host -> device staging of one stereo pair by a kernel that reads mapped host memory (96 KB):
+// the copy stays in the compute queue, where an SDMA copy costs a cross-engine dependency
+// (~6 us of a 55 us call).
+__global__ __launch_bounds__(256) void stage_in_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, u32 n16) {
+  const u32 i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = __builtin_nontemporal_load(src + i);
 }
 
 // One or two jobs handed over as kernel arguments (entry points that return before their work
