@@ -54,6 +54,9 @@
 // descriptors some lane has news in nearly every step: any wave-level test is defeated, the work
 // has to be the same in every step -- and small.  This form: 12.5 T on either kind of data, 7.4 T
 // on 333-descriptor images (3.9 T before).
+// (Tried again in round 2, no gain: train codes 0.0 / 1.0 instead of +-1.0 -- half-zero operands
+// draw less power and the bare instruction runs 10 % faster on them (tools/mfma_rate.hip), but this
+// kernel 2.4 % slower, 13.55 against 13.87 T; the offset pop(q) would ride in the start distance.)
 // Build with -mllvm -amdgpu-mfma-vgpr-form: the minimum tree reads the results with VALU
 // instructions, from AGPRs every element would first need a v_accvgpr_read.
 #pragma once
@@ -265,7 +268,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
 // queries and remainder tiles of half and a quarter of that, grouped or job-minor block order
 // (see there).  WAVES == 4: the grid of scan_kernel (4-wave workgroups, job-minor), used with
 // NBMAX == 2 for one stereo pair and for the pruned backward pass, most of whose workgroups find
-// nothing to do.
+// nothing to do.  Registers: 237 (NBMAX 8: two waves per SIMD), 166 (4: three), 117 (2: four).
 template <int NBMAX, int WAVES = 1>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
