@@ -11,6 +11,7 @@
 // reference's vocabulary file is not in its checkout (see include/vsmatch.h).
 #pragma once
 
+#include <atomic>
 #include <bitset>
 #include <cstdint>
 #include <stdexcept>
@@ -23,6 +24,18 @@
 #include "visnav_amd/keypoints_gpu.h"
 
 namespace visnav {
+namespace vsm_detail {
+// A library context holds ONE vocabulary tree, and the shim keeps one context per thread: which
+// vocabulary object (by a process-wide id, never reused) this thread's context holds.
+inline uint64_t& thread_voc_id() {
+  thread_local uint64_t id = 0;
+  return id;
+}
+inline uint64_t next_voc_id() {
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1);
+}
+}  // namespace vsm_detail
 
 class BowVocabularyGpu {
  public:
@@ -30,8 +43,9 @@ class BowVocabularyGpu {
   using WordValue = double;      // common_types.h:326
   using TDescriptor = std::bitset<256>;
 
-  explicit BowVocabularyGpu(const std::string& filename) : voc_(cereal_lite::read_vocabulary(filename)) {}
-  explicit BowVocabularyGpu(cereal_lite::Vocabulary voc) : voc_(std::move(voc)) {}
+  explicit BowVocabularyGpu(const std::string& filename)
+      : voc_(cereal_lite::read_vocabulary(filename)), id_(vsm_detail::next_voc_id()) {}
+  explicit BowVocabularyGpu(cereal_lite::Vocabulary voc) : voc_(std::move(voc)), id_(vsm_detail::next_voc_id()) {}
 
   size_t size() const { return voc_.size(); }
 
@@ -42,11 +56,14 @@ class BowVocabularyGpu {
     weights.assign(features.size(), 0);
     if (features.empty()) return;
     vsm_ctx* ctx = vsm_detail::thread_context();
-    if (uploaded_to_ != ctx) {  // one upload per context (= per calling thread)
+    // one upload per calling thread and vocabulary: re-uploaded when another BowVocabularyGpu used
+    // this thread's context in between (the state is per thread, nothing shared is written here)
+    if (vsm_detail::thread_voc_id() != id_) {
+      vsm_detail::thread_voc_id() = 0;
       if (vsm_voc_upload(ctx, voc_.node_desc.data(), voc_.child_off.data(), voc_.child_idx.data(),
                          voc_.node_id.data(), voc_.word_id.data(), voc_.weight.data(), voc_.size()) != VSM_OK)
         throw std::runtime_error(std::string("visnav::BowVocabularyGpu: ") + vsm_last_error());
-      uploaded_to_ = ctx;
+      vsm_detail::thread_voc_id() = id_;
     }
     if (vsm_bow_words(ctx, reinterpret_cast<const uint64_t*>(features.data()), features.size(), words.data(),
                       weights.data()) != VSM_OK)
@@ -79,7 +96,7 @@ class BowVocabularyGpu {
 
  private:
   cereal_lite::Vocabulary voc_;
-  mutable vsm_ctx* uploaded_to_ = nullptr;
+  uint64_t id_;
 };
 
 }  // namespace visnav

@@ -36,7 +36,29 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "FAIL: entry %zu\n", i);
         return 1;
       }
-    std::printf("bow shim ok: %zu nodes, %zu features -> %zu words\n", voc.size(), features.size(), bow.size());
+    // a second vocabulary on the same thread (a root with a single leaf, word id 7) takes over the
+    // thread's context; going back to the first must upload it again, not descend the other tree
+    visnav::cereal_lite::Vocabulary tiny;
+    tiny.node_desc.assign(8, 0);
+    tiny.child_off = {0, 1, 1};
+    tiny.child_idx = {1};
+    tiny.node_id = {0, 1};
+    tiny.word_id = {0, 7};
+    tiny.weight = {0.0, 2.5};
+    visnav::BowVocabularyGpu other(tiny);
+    std::vector<std::pair<unsigned int, double>> b2, b3;
+    other.transform(features, b2);
+    if (b2.size() != 1 || b2[0].first != 7 || b2[0].second != 1.0) {
+      std::fprintf(stderr, "FAIL: second vocabulary\n");
+      return 1;
+    }
+    voc.transform(features, b3);
+    if (b3 != bow) {
+      std::fprintf(stderr, "FAIL: first vocabulary after the second one used the same context\n");
+      return 1;
+    }
+    std::printf("bow shim ok: %zu nodes, %zu features -> %zu words; two vocabularies on one thread\n", voc.size(),
+                features.size(), bow.size());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "FAIL: %s\n", e.what());
     return 1;
