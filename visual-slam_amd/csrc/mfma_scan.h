@@ -57,6 +57,10 @@
 // (Tried again in round 2, no gain: train codes 0.0 / 1.0 instead of +-1.0 -- half-zero operands
 // draw less power and the bare instruction runs 10 % faster on them (tools/mfma_rate.hip), but this
 // kernel 2.4 % slower, 13.55 against 13.87 T; the offset pop(q) would ride in the start distance.)
+// (Tried in round 2, much slower: FP4 codes pre-expanded in HBM (128 B per descriptor, loaded
+// instead of expanded: 14.75 -> 11.25 VALU instructions per step) -- the four-fold operand traffic
+// from L2 costs more than the VALU work it saves: 10.1 against 13.9 T at 256-query tiles, 8.8
+// against 13.3 T at 128, 4.6 against 12.0 T at 64.)
 // Build with -mllvm -amdgpu-mfma-vgpr-form: the minimum tree reads the results with VALU
 // instructions, from AGPRs every element would first need a v_accvgpr_read.
 #pragma once
