@@ -1,6 +1,8 @@
 import os
 import sys
 
+import torch  # noqa: F401  (first: its bundled HIP runtime must be the process's one, see matcher.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

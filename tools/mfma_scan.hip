@@ -134,7 +134,8 @@ int main(int argc, char** argv) {
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
-  const V vs[] = {{"shipped NB8", 24, 8}, {"shipped NB4", 24, 4}, {"shipped NB2", 24, 2}};
+  const V vs[] = {{"shipped NB8", 24, 8}, {"shipped NB4", 24, 4}, {"shipped NB2", 24, 2},
+                  {"NB8, 4-wave workgroups", 44, 8}, {"NB4, 4-wave workgroups", 44, 4}};
 #else
   const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2},
                   {"mfma group NB8", 24, 8}, {"mfma group NB4", 24, 4}, {"mfma group NB2", 24, 2}};
@@ -148,6 +149,12 @@ int main(int argc, char** argv) {
       const dim3 g(groups * 8 * tiles), blk(64);
 #define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
 #ifdef VSM_PRODUCT
+      if (v.fmt == 44) {  // tiles of a job in one workgroup (one CU: they share its L1), job-minor order
+        const dim3 g4(n_jobs * ((tiles + 3) / 4)), b4(256);
+#define ARGS4 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, 0u, d_lim
+        if (v.nb == 8) mfma_scan_kernel<8, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr});
+        else mfma_scan_kernel<4, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr});
+      } else
       if (v.nb == 8) mfma_scan_kernel<8, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
       else if (v.nb == 4) mfma_scan_kernel<4, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
       else mfma_scan_kernel<2, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
@@ -167,7 +174,7 @@ int main(int argc, char** argv) {
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
     }
-    if (v.fmt == 24) {
+    if (v.fmt == 24 || v.fmt == 44) {
       CK(hipEventRecord(e0));
       refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr);
       CK(hipEventRecord(e1));

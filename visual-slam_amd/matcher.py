@@ -47,6 +47,30 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 
 
+def _share_the_hip_runtime_with_torch():
+    """PyTorch's ROCm wheels ship their own libamdhip64.so.7 (and HSA runtime); libvsmatch.so links
+    the system's /opt/rocm one of the same SONAME.  A process can hold only one of them: whichever is
+    loaded first serves both, and PyTorch on the system's newer runtime fails ("No HIP GPUs are
+    available").  So when PyTorch is installed -- whether or not it has been imported yet -- its
+    runtime is loaded first and libvsmatch.so binds to it.  Without PyTorch: the system's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads libvsmatch.so (built by __graft_entry__.build()); raises if absent."""
     global _lib
@@ -54,6 +78,7 @@ def lib():
         if _lib is None:
             if not os.path.exists(LIB_PATH):
                 raise VsmError(VSM_ERR_HIP, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            _share_the_hip_runtime_with_torch()
             L = C.CDLL(LIB_PATH)
             L.vsm_version.restype = C.c_int
             L.vsm_last_error.restype = C.c_char_p
