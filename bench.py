@@ -70,8 +70,8 @@ BLOCK = 4096  # pairs per block of the block-cyclic partition (sfm_pairs.BLOCK)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--images", type=int, default=5000)
     ap.add_argument("--desc", type=int, default=2000)
     ap.add_argument("--pairs", type=int, default=32768, help="image pairs per rank per step (weak scaling)")

@@ -8,7 +8,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --steps 3 --warmup 1 --no-extra --cpu-pairs 0"
+ARGS="bench.py --steps 6 --warmup 3 --no-extra --cpu-pairs 0"
 echo "$ARGS" > $OUT/command.txt
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.json 2> $OUT/trace.err
 timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o p -- python3 $ARGS > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err || echo "pmc_mfma pass failed"

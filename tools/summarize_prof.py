@@ -27,8 +27,16 @@ with open(os.path.join(dst, "kernel_trace_stats.txt"), "w") as f:
     for name, calls, total, avg, pct in top:
         f.write(f"{name.split('(')[0]:60s} {calls:6d} {total:14.1f} {avg:12.1f} {pct:8.3f}\n")
     r = line["roofline"]
-    f.write(f"# the bench line of this same (profiled) run: avg_launch_ms {r['avg_launch_ms']:.3f} (HIP events), "
-            f"kernel {r['kernel_gcomps']:.0f} G comparisons/s, roofline.frac {r['frac']:.4f}\n")
+    # --stats averages every launch; bench.py's HIP events average the timed ones only (the first
+    # `warmup` launches run at a lower clock: same cycle count, see pmc_counters.txt)
+    durs = [(e - b) / 1e3 for b, e in q(os.path.join(src, "trace", "t_results.db"),
+            f"select start, end from kernels where name like '%{DOMINANT}%' order by start")]
+    warm = int(line["warmup"])
+    timed_us = sum(durs[warm:]) / max(1, len(durs[warm:]))
+    f.write(f"# {DOMINANT}, every launch in us: {' '.join(f'{d:.1f}' for d in durs)}  (the first {warm} = warm-up, untimed by bench.py)\n")
+    f.write(f"# average of the {len(durs) - warm} timed launches: {timed_us:.1f} us by the kernel trace; the bench line of this same "
+            f"(profiled) run: avg_launch_ms {r['avg_launch_ms']:.3f} by HIP events, kernel {r['kernel_gcomps']:.0f} G comparisons/s, "
+            f"roofline.frac {r['frac']:.4f}\n")
 
 ex = os.path.join(src, "trace_extras", "t_results.db")
 if os.path.exists(ex):
@@ -50,11 +58,25 @@ with open(os.path.join(dst, "pmc_counters.txt"), "w") as f:
         for name, c, n, avg in q(p, "select kernel_name, counter_name, count(*), avg(value) from counters_collection "
                                     "group by kernel_name, counter_name order by kernel_name, counter_name"):
             f.write(f"{name.split('(')[0]:50s} {c:26s} {n:4d} {avg:20.1f}\n")
-            if DOMINANT in name:
-                ctr[(d, c)] = avg
+        # the dominant kernel: timed launches only, with the duration of each launch IN THIS PASS
+        rows = q(p, f"select dispatch_id, counter_name, value, end - start from counters_collection where kernel_name like '%{DOMINANT}%' "
+                    "order by dispatch_id")
+        ids = sorted({r[0] for r in rows})[warm:]
+        for c in {r[1] for r in rows}:
+            vals = [r[2] for r in rows if r[1] == c and r[0] in ids]
+            ctr[(d, c)] = sum(vals) / len(vals)
+        if d == "pmc_mfma":
+            per = {i: {r[1]: (r[2], r[3]) for r in rows if r[0] == i} for i in ids}
+            f.write(f"# {DOMINANT} in the pmc_mfma pass, launch by launch (all {len(ids) + warm}, the first {warm} = warm-up): duration us | GRBM_GUI_ACTIVE / 8 XCDs | clock GHz\n")
+            for i in sorted({r[0] for r in rows}):
+                g_, ns = [(r[2], r[3]) for r in rows if r[0] == i and r[1] == "GRBM_GUI_ACTIVE"][0]
+                f.write(f"#   {ns / 1e3:10.1f} {g_ / XCDS:14.0f} {g_ / XCDS / ns:8.3f}\n")
+            clk = [per[i]["GRBM_GUI_ACTIVE"][0] / XCDS / per[i]["GRBM_GUI_ACTIVE"][1] for i in ids]
+            ctr[("pmc_mfma", "clock_ghz")] = sum(clk) / len(clk)
 
 avg_us = [avg for name, calls, total, avg, pct in top if DOMINANT in name][0]
-s = {"kernel": DOMINANT, "command": cmd, "pairs_per_launch": pairs, "avg_launch_us_kernel_trace": avg_us,
+s = {"kernel": DOMINANT, "command": cmd, "pairs_per_launch": pairs, "avg_launch_us_kernel_trace": timed_us,
+     "avg_launch_us_kernel_trace_with_warmup_launches": avg_us,
      "avg_launch_ms_hip_events_same_run": line["roofline"]["avg_launch_ms"]}
 if ("pmc_fetch", "FETCH_SIZE") in ctr and ("pmc_write", "WRITE_SIZE") in ctr:
     s["FETCH_SIZE_KB_per_launch"] = ctr[("pmc_fetch", "FETCH_SIZE")]
@@ -66,7 +88,7 @@ if g and b:
     s["GRBM_GUI_ACTIVE_per_launch"] = g
     s["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] = b
     s["SQ_INSTS_MFMA_per_launch"] = ctr.get(("pmc_mfma", "SQ_INSTS_MFMA"))
-    s["sustained_clock_ghz"] = g / XCDS / (avg_us * 1e-6) / 1e9
+    s["sustained_clock_ghz"] = ctr[("pmc_mfma", "clock_ghz")]
     s["mfma_busy_frac"] = (b / SIMDS) / (g / XCDS)
 v = ctr.get(("pmc_sq", "SQ_INSTS_VALU"))
 if v and s.get("SQ_INSTS_MFMA_per_launch"):
@@ -74,8 +96,8 @@ if v and s.get("SQ_INSTS_MFMA_per_launch"):
 s["note"] = ("rocprofv3 --pmc, one pass per counter group (tools/profile_bench.sh); raw FETCH_SIZE / WRITE_SIZE in KiB. "
              "hbm_bytes_per_pair = (2 x FETCH_SIZE + WRITE_SIZE) / pairs: the x2 gfx950 correction of MI355X_MICROARCH.md "
              "(FETCH_SIZE reports half the bytes of 16 B/lane global loads) applies, the scan reads every descriptor through "
-             "global_load_dwordx4; WRITE_SIZE is exact (8 B per query).  sustained_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / "
-             "kernel-trace duration; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).")
+             "global_load_dwordx4; WRITE_SIZE is exact (8 B per query).  Timed launches only (bench.py's warm-up launches run the same cycle count at a lower clock).  "
+             "sustained_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / the duration of the same dispatch in the counter pass; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).")
 json.dump(s, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_trace_stats.txt")).read())
 print(json.dumps(s, indent=1))
