@@ -206,6 +206,76 @@ class _Matcher:
         return ang, desc
 
 
+class BowDb:
+    """visnav::BowDatabase (bow_db.h:45-168) as restated in oracle/vsm_oracle_bowdb.cpp; port only."""
+
+    def __init__(self):
+        lib = port()._lib
+        self._lib = lib
+        lib.vsm_oracle_bowdb_new.restype = C.c_void_p
+        lib.vsm_oracle_bowdb_free.argtypes = [C.c_void_p]
+        lib.vsm_oracle_bowdb_clear.argtypes = [C.c_void_p]
+        lib.vsm_oracle_bowdb_insert.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, _u32p, _f64p, C.c_size_t]
+        lib.vsm_oracle_bowdb_query.restype = C.c_size_t
+        lib.vsm_oracle_bowdb_query.argtypes = [C.c_void_p, _u32p, _f64p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_uint64), _f64p, C.c_size_t]
+        self._h = C.c_void_p(lib.vsm_oracle_bowdb_new())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.vsm_oracle_bowdb_free(self._h)
+            self._h = None
+
+    def clear(self):
+        self._lib.vsm_oracle_bowdb_clear(self._h)
+
+    @staticmethod
+    def _vec(words, values):
+        w = np.ascontiguousarray(words, dtype=np.uint32)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert w.shape == v.shape and w.ndim == 1
+        return w, v
+
+    def insert(self, fcid, words, values):
+        w, v = self._vec(words, values)
+        self._lib.vsm_oracle_bowdb_insert(self._h, int(fcid[0]), int(fcid[1]), w.ctypes.data_as(_u32p),
+                                          v.ctypes.data_as(_f64p), len(w))
+
+    def query(self, words, values, num_results):
+        """-> (fcid int64[n, 2], score float64[n]) in the reference's result order."""
+        w, v = self._vec(words, values)
+        cap = 1024
+        while True:
+            fr, cam, sc = np.zeros(cap, np.int64), np.zeros(cap, np.uint64), np.zeros(cap, np.float64)
+            n = self._lib.vsm_oracle_bowdb_query(self._h, w.ctypes.data_as(_u32p), v.ctypes.data_as(_f64p), len(w),
+                                                 int(num_results), fr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                 cam.ctypes.data_as(C.POINTER(C.c_uint64)), sc.ctypes.data_as(_f64p), cap)
+            if n <= cap:
+                return np.stack([fr[:n], cam[:n].astype(np.int64)], axis=1), sc[:n].copy()
+            cap = n
+
+
+def match_bow_pairs(fcids, vec_off, words, values, num_candidates):
+    """The pair selection of match_bow (src/sfm.cpp:1366-1392) -> (pairs int32[n, 2], score float64[n]):
+    (image, earlier image) in the reference's order, with the L1 score the query gave."""
+    lib = port()._lib
+    f = lib.vsm_oracle_match_bow_pairs
+    f.restype = C.c_size_t
+    f.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_uint64), _u32p, _u32p, _f64p, C.c_size_t, C.c_size_t, _i32p, _f64p, C.c_size_t]
+    fr = np.ascontiguousarray([x[0] for x in fcids], dtype=np.int64)
+    cam = np.ascontiguousarray([x[1] for x in fcids], dtype=np.uint64)
+    off = np.ascontiguousarray(vec_off, dtype=np.uint32)
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    cap = max(1, len(fr) * int(num_candidates))
+    pairs, sc = np.zeros((cap, 2), np.int32), np.zeros(cap, np.float64)
+    n = f(fr.ctypes.data_as(C.POINTER(C.c_int64)), cam.ctypes.data_as(C.POINTER(C.c_uint64)), off.ctypes.data_as(_u32p),
+          w.ctypes.data_as(_u32p), v.ctypes.data_as(_f64p), len(fr), int(num_candidates), pairs.ctypes.data_as(_i32p),
+          sc.ctypes.data_as(_f64p), cap)
+    assert n <= cap
+    return pairs[:n].copy(), sc[:n].copy()
+
+
 _cache = {}
 
 

@@ -484,6 +484,67 @@ def match_data_to_json(md, indent=4):
 
 
 # ----------------------------------------------------------------------------
+# BoW database (bow_db.h:135-160: JSON archive of BowDBInverseIndex =
+# unordered_map<WordId, vector<pair<FrameCamId, WordValue>>>, common_types.h:336-337) and the
+# reference test's distance matrix (test_ex3.cpp:615-619: binary archive of a dynamic Eigen
+# matrix of pair<FrameCamId, double>, serialization.h:57-90)
+
+def bow_db_from_json(obj):
+    """-> [(word, [((frame_id, cam_id), value), ...]), ...] in the archive's order."""
+    return [(int(e["key"]), [((int(p["first"]["value0"]), int(p["first"]["value1"])), float(p["second"]))
+                             for p in e["value"]]) for e in obj["value0"]]
+
+
+def load_bow_db_json(path):
+    with open(path) as f:
+        return bow_db_from_json(json.load(f))
+
+
+def bow_db_to_json(index, indent=4):
+    """BowDatabase::save (bow_db.h:135-146)."""
+    return json.dumps({"value0": [{"key": int(w), "value": [{"first": {"value0": int(fc[0]), "value1": int(fc[1])},
+                                                            "second": float(v)} for fc, v in lst]}
+                                  for w, lst in index]}, indent=indent)
+
+
+def save_bow_db_json(path, index):
+    with open(path, "w") as f:
+        f.write(bow_db_to_json(index))
+
+
+def bow_db_to_vectors(index):
+    """The inverted index turned back into one BoW vector per image: {fcid: [(word, value), ...]}, the
+    words of an image in the archive's order (the order inside the reference's BowVector is not
+    recoverable from the index; it only decides the rounding of the L1 score)."""
+    out = {}
+    for w, lst in index:
+        for fc, v in lst:
+            out.setdefault(fc, []).append((w, v))
+    return out
+
+
+def load_bow_dist_binary(path):
+    """-> (fcid int64[rows, cols, 2], dist float64[rows, cols])."""
+    r = BinaryReader(_read(path))
+    rows, cols = r.i32(), r.i32()
+    if rows < 0 or cols < 0:
+        raise ValueError("negative matrix size")
+    rec = r.array(np.dtype([("f", "<i8"), ("c", "<u8"), ("d", "<f8")]), rows * cols).reshape(rows, cols)
+    _finish(r, "bow distance matrix", path)
+    return np.stack([rec["f"], rec["c"].astype(np.int64)], axis=-1), rec["d"].copy()
+
+
+def bow_vectors_to_csr(vectors):
+    """[[(word, value), ...], ...] -> (off uint32[n + 1], words uint32[total], values float64[total]):
+    the `vsm_bowdb_upload` / `vsm_bowdb_query` layout (include/vsmatch.h)."""
+    off = np.zeros(len(vectors) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(v) for v in vectors])
+    words = np.array([w for v in vectors for w, _ in v], dtype=np.uint32)
+    values = np.array([x for v in vectors for _, x in v], dtype=np.float64)
+    return off, words, values
+
+
+# ----------------------------------------------------------------------------
 # flattening for the C ABI
 
 def corners_to_database(items):
