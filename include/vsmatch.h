@@ -261,6 +261,40 @@ int vsm_voc_upload(vsm_ctx* ctx, const uint64_t* node_desc, const uint32_t* chil
 int vsm_bow_words(vsm_ctx* ctx, const uint64_t* desc, size_t n, uint32_t* word_out, double* weight_out);
 
 /*
+ * visnav::BowDatabase (include/visnav/bow_db.h:45-168) for a whole image set.
+ *
+ * vsm_bowdb_upload replaces clear() + insert() (bow_db.h:49-61, 133) of images 0 .. n_img-1 IN THIS
+ * ORDER: image i's BoW vector is (words[k], values[k]), k in [vec_off[i], vec_off[i+1]), as
+ * BowVocabulary::transform returns it (a word at most once per image, values L1-normalised; word
+ * ids < 2^26, values finite: VSM_ERR_INVALID otherwise).  An image is known by its index; the caller
+ * keeps the FrameCamId of each.  HOST pointers, copied.
+ *
+ * vsm_bowdb_query replaces query() (bow_db.h:63-131) for n_q BoW vectors at once (same layout):
+ * the L1 distance 2 + sum over common words of (|q - v| - |q| - |v|) to every image sharing a word
+ * with the query, accumulated in the order of the query's words exactly as the reference
+ * accumulates it (doubles: same additions, same order, same result bits), and of those the
+ * num_results nearest.  db_limit (may be NULL = all): query q only sees images [0, db_limit[q]) --
+ * the state of the reference's database after that many insert() calls.  Results of query q:
+ * out_n[q] = how many (<= num_results), out_idx / out_score [q * num_results + r] ascending by
+ * score; unused entries -1 / 0.  The reference leaves the order of EQUAL scores to std::sort and its
+ * hash map (its own test says so, test/src/test_ex3.cpp:523-525); here the lower image index comes
+ * first, so at a tie across the cut another image of the same score may be chosen.
+ *
+ * vsm_bow_select_pairs replaces the pair selection of match_bow (src/sfm.cpp:1366-1392) over the
+ * uploaded images: image k queries images 0 .. k-1 (query, then insert), and every result of
+ * another frame id becomes the pair (k, result) -- first index the querying image, as the reference
+ * passes them to matchDescriptors (sfm.cpp:1401-1411); ready for vsm_match_pairs.  Order: by k, then
+ * by score.  VSM_ERR_CAPACITY with *n_pairs = the need if cap is too small.
+ */
+int vsm_bowdb_upload(vsm_ctx* ctx, const uint32_t* vec_off, const uint32_t* words, const double* values,
+                     size_t n_img);
+int vsm_bowdb_query(vsm_ctx* ctx, const uint32_t* q_off, const uint32_t* q_words, const double* q_values,
+                    size_t n_q, const uint32_t* db_limit, size_t num_results, int32_t* out_idx,
+                    double* out_score, uint32_t* out_n);
+int vsm_bow_select_pairs(vsm_ctx* ctx, const int64_t* frame_id, size_t num_candidates,
+                         uint32_t (*pairs)[2], size_t cap, size_t* n_pairs);
+
+/*
  * Measurement hooks (bench.py): wall time in ms of the scan kernel launches of
  * the last batched/nn2 call, measured with HIP events on the context's stream,
  * how many launches that was and how many 256-bit comparisons they evaluated.

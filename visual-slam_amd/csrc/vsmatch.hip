@@ -9,6 +9,7 @@
 #include "orb_kernels.h"
 #include "gftt_kernels.h"
 #include "bow_kernels.h"
+#include "bowdb_kernels.h"
 
 #include <algorithm>
 #include <atomic>
@@ -151,6 +152,11 @@ struct vsm_ctx {
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
   DevBuf voc;          // vocabulary tree (vsm_voc_upload)
   size_t voc_nodes = 0, voc_off[6] = {0, 0, 0, 0, 0, 0};
+  // BoW database (vsm_bowdb_upload): inverted index by word + the images' own vectors
+  DevBuf bowdb, bowdb_work;
+  size_t bowdb_off[6] = {0, 0, 0, 0, 0, 0}, bowdb_entries = 0;
+  u32 bowdb_images = 0, bowdb_dense = 0;
+  bool bowdb_ready = false;
   PinBuf pin, pin_image;
   // vsm_match_pair's results: host memory the emit kernel writes directly (mapped, coherent), so the
   // call needs no device-to-host copy and can poll a flag instead of waiting on the stream
@@ -635,7 +641,7 @@ void vsm_destroy(vsm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist, &c->flist, &c->accmask, &c->lut,
-                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc})
+                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc, &c->bowdb, &c->bowdb_work})
       b->release();
     c->pin.release();
     c->pin_image.release();
@@ -1560,6 +1566,210 @@ int vsm_bow_words(vsm_ctx* c, const uint64_t* desc, size_t n, uint32_t* word_out
                                  "the reference's loop (bow_voc.h:77-88) does not terminate there");
   memcpy(word_out, hd + o_w, n * 4);
   memcpy(weight_out, hd + o_v, n * 8);
+  return VSM_OK;
+}
+
+// ---- BoW database (bow_db.h) ------------------------------------------------------------------
+
+}  // extern "C"
+
+namespace {
+
+constexpr u32 BOWDB_MAX_WORD = 1u << 26;              // dense word table: 4 B per word id
+constexpr size_t BOWDB_WORK_BUDGET = (size_t)256 << 20;  // score rows + candidate lists per launch
+
+int check_bow_vectors(const uint32_t* off, const uint32_t* words, const double* values, size_t n, const char* what) {
+  if (!off) return fail(VSM_ERR_INVALID, "null %s offsets", what);
+  if (off[0] != 0) return fail(VSM_ERR_INVALID, "%s offsets must start at 0", what);
+  for (size_t i = 0; i < n; i++)
+    if (off[i + 1] < off[i]) return fail(VSM_ERR_INVALID, "%s offsets not ascending at %zu", what, i);
+  const size_t total = off[n];
+  if (total && (!words || !values)) return fail(VSM_ERR_INVALID, "null %s words or values", what);
+  for (size_t k = 0; k < total; k++)
+    if (!std::isfinite(values[k])) return fail(VSM_ERR_INVALID, "%s value %zu is not finite", what, k);
+  return VSM_OK;
+}
+
+// Queries already on the device (d_q*: offsets, words, values of n_q vectors); limit: nullptr = every
+// image, else per query; limit_iota: query k sees the images before k.  Results into host arrays
+// with the caller's stride num_results.
+int bowdb_query_device(vsm_ctx* c, const u32* d_qoff, const u32* d_qwords, const double* d_qvals, size_t n_q,
+                       const u32* d_limit, bool limit_iota, size_t num_results, int32_t* out_idx, double* out_score,
+                       uint32_t* out_n) {
+  const size_t n_img = c->bowdb_images;
+  const u32 nr = (u32)std::min<size_t>(num_results, n_img);
+  for (size_t i = 0; i < n_q * num_results; i++) out_idx[i] = -1;
+  for (size_t i = 0; i < n_q * num_results; i++) out_score[i] = 0.0;
+  for (size_t i = 0; i < n_q; i++) out_n[i] = 0;
+  if (n_q == 0 || nr == 0) return VSM_OK;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  // score row in LDS when it fits (one LDS round trip per word instead of one through HBM)
+  const bool lds_row = n_img <= BOWDB_LDS_MAX_IMAGES;
+  const size_t lds_bytes = BOWDB_LDS_FIXED + (lds_row ? n_img * 8 : 0);
+  auto kernel = lds_row ? bowdb_query_kernel<true> : bowdb_query_kernel<false>;
+  if (lds_bytes > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  const size_t per_query = n_img * (lds_row ? 24 : 32);  // candidates + survivors (+ the row)
+  const size_t chunk = std::max<size_t>(1, std::min<size_t>(n_q, BOWDB_WORK_BUDGET / std::max<size_t>(per_query, 1)));
+  const size_t o_rows = 0, o_cs = o_rows + (lds_row ? 0 : al(chunk * n_img * 8)), o_ss = o_cs + al(chunk * n_img * 8),
+               o_ci = o_ss + al(chunk * n_img * 8), o_si = o_ci + al(chunk * n_img * 4), o_oi = o_si + al(chunk * n_img * 4),
+               o_os = o_oi + al(n_q * nr * 4), o_on = o_os + al(n_q * nr * 8), total = o_on + al(n_q * 4);
+  VSM_TRY(c->bowdb_work.reserve(total));
+  char* w = (char*)c->bowdb_work.p;
+  const char* d = (const char*)c->bowdb.p;
+  const size_t* o = c->bowdb_off;
+  for (size_t q0 = 0; q0 < n_q; q0 += chunk) {
+    const u32 nq = (u32)std::min(chunk, n_q - q0);
+    hipLaunchKernelGGL(kernel, dim3(nq), dim3(64), lds_bytes, c->stream, d_qoff, d_qwords, d_qvals, (u32)q0, d_limit,
+                       limit_iota ? 1u : 0u, (const u32*)(d + o[0]), c->bowdb_dense, (const u32*)(d + o[1]),
+                       (const double*)(d + o[2]), (u32)n_img, (double*)(w + o_rows), (u32*)(w + o_ci),
+                       (double*)(w + o_cs), (u32*)(w + o_si), (double*)(w + o_ss), nr, (int*)(w + o_oi),
+                       (double*)(w + o_os), (u32*)(w + o_on));
+    HIP_TRY(hipGetLastError());
+  }
+  const size_t down = total - o_oi;
+  VSM_TRY(c->pin.reserve(down));
+  char* h = (char*)c->pin.p;
+  HIP_TRY(hipMemcpyAsync(h, w + o_oi, down, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int32_t* hi = (const int32_t*)h;
+  const double* hs = (const double*)(h + (o_os - o_oi));
+  const uint32_t* hn = (const uint32_t*)(h + (o_on - o_oi));
+  for (size_t q = 0; q < n_q; q++) {
+    out_n[q] = hn[q];
+    for (u32 r = 0; r < hn[q]; r++) {  // only the first out_n entries of a row were written
+      out_idx[q * num_results + r] = hi[q * nr + r];
+      out_score[q * num_results + r] = hs[q * nr + r];
+    }
+  }
+  return VSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsm_bowdb_upload(vsm_ctx* c, const uint32_t* vec_off, const uint32_t* words, const double* values, size_t n_img) {
+  VSM_TRY(check_ctx(c));
+  if (n_img >= 0x7fffffffull) return fail(VSM_ERR_INVALID, "more than 2^31 images");
+  VSM_TRY(check_bow_vectors(vec_off, words, values, n_img, "database"));
+  const size_t total = vec_off[n_img];
+  u32 max_word = 0;
+  for (size_t k = 0; k < total; k++) max_word = std::max(max_word, words[k]);
+  if (total && max_word >= BOWDB_MAX_WORD) return fail(VSM_ERR_INVALID, "word id %u: the word table is dense, ids must be < 2^26", max_word);
+  const size_t n_dense = total ? (size_t)max_word + 1 : 0;
+  // insert() of the images in order (bow_db.h:55-60) = a counting sort by word that keeps image order
+  std::vector<u32> start(n_dense + 1, 0), inv_img(total);
+  std::vector<double> inv_val(total);
+  {
+    std::vector<u32> seen(n_dense, 0);  // last image (+1) that named the word: the reference's BowVector has a word once
+    for (size_t i = 0; i < n_img; i++)
+      for (size_t k = vec_off[i]; k < vec_off[i + 1]; k++) {
+        if (seen[words[k]] == i + 1) return fail(VSM_ERR_INVALID, "image %zu names word %u twice", i, words[k]);
+        seen[words[k]] = (u32)i + 1;
+        start[words[k] + 1]++;
+      }
+    for (size_t w = 0; w < n_dense; w++) start[w + 1] += start[w];
+    std::vector<u32> fill(start.begin(), start.end() - 1);
+    for (size_t i = 0; i < n_img; i++)
+      for (size_t k = vec_off[i]; k < vec_off[i + 1]; k++) {
+        const u32 at = fill[words[k]]++;
+        inv_img[at] = (u32)i;
+        inv_val[at] = values[k];
+      }
+  }
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  c->bowdb_ready = false;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t* o = c->bowdb_off;  // inv_start | inv_img | inv_val | vec_off | words | values
+  o[0] = 0;
+  o[1] = o[0] + al((n_dense + 1) * 4);
+  o[2] = o[1] + al(std::max<size_t>(total, 1) * 4);
+  o[3] = o[2] + al(std::max<size_t>(total, 1) * 8);
+  o[4] = o[3] + al((n_img + 1) * 4);
+  o[5] = o[4] + al(std::max<size_t>(total, 1) * 4);
+  VSM_TRY(c->bowdb.reserve(o[5] + al(std::max<size_t>(total, 1) * 8)));
+  char* d = (char*)c->bowdb.p;
+  HIP_TRY(hipMemcpyAsync(d + o[0], start.data(), (n_dense + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(d + o[3], vec_off, (n_img + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (total) {
+    HIP_TRY(hipMemcpyAsync(d + o[1], inv_img.data(), total * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d + o[2], inv_val.data(), total * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d + o[4], words, total * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d + o[5], values, total * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the sources are pageable host memory of this call
+  c->bowdb_images = (u32)n_img;
+  c->bowdb_dense = (u32)n_dense;
+  c->bowdb_entries = total;
+  c->bowdb_ready = true;
+  return VSM_OK;
+}
+
+int vsm_bowdb_query(vsm_ctx* c, const uint32_t* q_off, const uint32_t* q_words, const double* q_values, size_t n_q,
+                    const uint32_t* db_limit, size_t num_results, int32_t* out_idx, double* out_score, uint32_t* out_n) {
+  VSM_TRY(check_ctx(c));
+  if (n_q == 0) return VSM_OK;
+  if (n_q >= 0x7fffffffull) return fail(VSM_ERR_INVALID, "more than 2^31 queries");
+  if (!out_n || (num_results && (!out_idx || !out_score))) return fail(VSM_ERR_INVALID, "null output");
+  VSM_TRY(check_bow_vectors(q_off, q_words, q_values, n_q, "query"));
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (!c->bowdb_ready) return fail(VSM_ERR_INVALID, "no BoW database: call vsm_bowdb_upload first");
+  const size_t total = q_off[n_q];
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_off = 0, o_w = al((n_q + 1) * 4), o_v = o_w + al(std::max<size_t>(total, 1) * 4),
+               o_l = o_v + al(std::max<size_t>(total, 1) * 8), up = o_l + al(n_q * 4);
+  VSM_TRY(c->pin.reserve(up));
+  VSM_TRY(c->stage.reserve(up));
+  char* h = (char*)c->pin.p;
+  memcpy(h + o_off, q_off, (n_q + 1) * 4);
+  if (total) {
+    memcpy(h + o_w, q_words, total * 4);
+    memcpy(h + o_v, q_values, total * 8);
+  }
+  if (db_limit) memcpy(h + o_l, db_limit, n_q * 4);
+  HIP_TRY(hipMemcpyAsync(c->stage.p, h, up, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // bowdb_query_device reuses the pinned buffer for the results
+  const char* s = (const char*)c->stage.p;
+  return bowdb_query_device(c, (const u32*)(s + o_off), (const u32*)(s + o_w), (const double*)(s + o_v), n_q,
+                            db_limit ? (const u32*)(s + o_l) : nullptr, false, num_results, out_idx, out_score, out_n);
+}
+
+int vsm_bow_select_pairs(vsm_ctx* c, const int64_t* frame_id, size_t num_candidates, uint32_t (*pairs)[2], size_t cap,
+                         size_t* n_pairs) {
+  VSM_TRY(check_ctx(c));
+  if (!n_pairs) return fail(VSM_ERR_INVALID, "null n_pairs");
+  *n_pairs = 0;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (!c->bowdb_ready) return fail(VSM_ERR_INVALID, "no BoW database: call vsm_bowdb_upload first");
+  const size_t n = c->bowdb_images;
+  if (n == 0 || num_candidates == 0) return VSM_OK;
+  if (!frame_id) return fail(VSM_ERR_INVALID, "null frame_id");
+  const size_t nr = std::min(num_candidates, n);
+  std::vector<int32_t> idx(n * nr);
+  std::vector<double> score(n * nr);
+  std::vector<uint32_t> cnt(n);
+  const char* d = (const char*)c->bowdb.p;
+  const size_t* o = c->bowdb_off;
+  // sfm.cpp:1373-1392: image k is queried against the images inserted before it, then inserted
+  VSM_TRY(bowdb_query_device(c, (const u32*)(d + o[3]), (const u32*)(d + o[4]), (const double*)(d + o[5]), n, nullptr,
+                             true, nr, idx.data(), score.data(), cnt.data()));
+  size_t m = 0;
+  for (size_t k = 0; k < n; k++)
+    for (u32 r = 0; r < cnt[k]; r++) {
+      const int32_t j = idx[k * nr + r];
+      if (frame_id[k] == frame_id[j]) continue;  // sfm.cpp:1386: stereo partners are not paired here
+      if (m < cap && pairs) {
+        pairs[m][0] = (uint32_t)k;
+        pairs[m][1] = (uint32_t)j;
+      }
+      m++;
+    }
+  *n_pairs = m;
+  if (m > cap) return fail(VSM_ERR_CAPACITY, "%zu pairs, capacity %zu", m, cap);
   return VSM_OK;
 }
 

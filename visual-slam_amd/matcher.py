@@ -32,6 +32,7 @@ SYMBOLS = (
     "vsm_orb_describe", "vsm_orb_angles", "vsm_orb_descriptors",
     "vsm_detect_keypoints", "vsm_good_features_to_track", "vsm_detect_and_describe",
     "vsm_voc_upload", "vsm_bow_words",
+    "vsm_bowdb_upload", "vsm_bowdb_query", "vsm_bow_select_pairs",
 )
 
 
@@ -112,6 +113,9 @@ def lib():
                                                   _sz, C.POINTER(_sz)]
             L.vsm_voc_upload.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]
             L.vsm_bow_words.argtypes = [_vp, _vp, _sz, _vp, _vp]
+            L.vsm_bowdb_upload.argtypes = [_vp, _vp, _vp, _vp, _sz]
+            L.vsm_bowdb_query.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp]
+            L.vsm_bow_select_pairs.argtypes = [_vp, _vp, _sz, _vp, _sz, C.POINTER(_sz)]
             L.vsm_orb_angles.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _sz, C.c_int, _vp]
             L.vsm_orb_descriptors.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, _vp, _vp, _sz, _vp]
             L.vsm_match_landmarks.argtypes = [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, C.c_double, C.c_int,
@@ -382,6 +386,59 @@ class Matcher:
         appearance, zero-weight words skipped, L1-normalised; words found on the GPU, the few
         hundred double additions done here in the reference's order."""
         return bow_vector(*self.bow_words(desc))
+
+    # -- bow_db.h:45-168, sfm.cpp:1366-1392 -----------------------------------------
+    @staticmethod
+    def _bow_csr(vectors):
+        """[[(word, value), ...], ...] or an (off, words, values) triple -> contiguous arrays."""
+        if isinstance(vectors, tuple) and len(vectors) == 3:
+            off, words, values = vectors
+        else:
+            off = np.zeros(len(vectors) + 1, dtype=np.uint32)
+            off[1:] = np.cumsum([len(v) for v in vectors])
+            words = [w for v in vectors for w, _ in v]
+            values = [x for v in vectors for _, x in v]
+        off = np.ascontiguousarray(off, dtype=np.uint32)
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        if off.ndim != 1 or len(off) < 1 or len(words) != len(values) or (len(off) and int(off[-1]) != len(words)):
+            raise ValueError("BoW vector arrays disagree in length")
+        return off, words, values
+
+    def bowdb_upload(self, vectors):
+        """BowDatabase::clear + insert (bow_db.h:49-61) of images 0 .. n-1 in this order; `vectors`:
+        one BowVector [(word, value), ...] per image, or (off uint32[n+1], words, values)."""
+        off, words, values = self._bow_csr(vectors)
+        _check(lib().vsm_bowdb_upload(self._h, _ptr(off), _ptr(words), _ptr(values), len(off) - 1))
+        self._bowdb_images = len(off) - 1
+
+    def bowdb_query(self, vectors, num_results, db_limit=None):
+        """BowDatabase::query (bow_db.h:63-131) for every vector -> list of (index int32[k], score
+        float64[k]) ascending by score (equal scores: lower image index first).  db_limit: per query,
+        how many of the first images it sees."""
+        off, words, values = self._bow_csr(vectors)
+        n_q, nr = len(off) - 1, int(num_results)
+        idx = np.full((n_q, nr), -1, dtype=np.int32)
+        score = np.zeros((n_q, nr), dtype=np.float64)
+        cnt = np.zeros(n_q, dtype=np.uint32)
+        lim = None if db_limit is None else np.ascontiguousarray(db_limit, dtype=np.uint32)
+        if lim is not None and len(lim) != n_q:
+            raise ValueError("one db_limit per query")
+        _check(lib().vsm_bowdb_query(self._h, _ptr(off), _ptr(words), _ptr(values), n_q,
+                                     None if lim is None else _ptr(lim), nr, _ptr(idx), _ptr(score), _ptr(cnt)))
+        return [(idx[q, :cnt[q]].copy(), score[q, :cnt[q]].copy()) for q in range(n_q)]
+
+    def bow_select_pairs(self, frame_ids, num_candidates=25):
+        """The pair selection of match_bow (sfm.cpp:1366-1392; num_bow_candidates = 25, sfm.cpp:209) over
+        the uploaded images -> uint32[n, 2] of (image, earlier image), ready for match_pairs."""
+        fr = np.ascontiguousarray(frame_ids, dtype=np.int64)
+        if len(fr) != getattr(self, "_bowdb_images", -1):
+            raise ValueError("one frame id per uploaded image")
+        cap = max(1, len(fr) * min(int(num_candidates), max(len(fr), 1)))
+        pairs = np.zeros((cap, 2), dtype=np.uint32)
+        n = _sz(0)
+        _check(lib().vsm_bow_select_pairs(self._h, _ptr(fr), int(num_candidates), _ptr(pairs), cap, C.byref(n)))
+        return pairs[:n.value].copy()
 
     # -- measurement ------------------------------------------------------------
     def set_profiling(self, on: bool):

@@ -248,3 +248,34 @@ def _parents(child_off, child_idx, n_nodes):
     counts = np.diff(child_off.astype(np.int64))
     parent[child_idx] = np.repeat(np.arange(n_nodes, dtype=np.uint32), counts)
     return parent
+
+
+def bow_vectors(n_img: int, n_words: int, words_per_image: int, seed: int, window: int = 8, share_frac: float = 0.5):
+    """BoW vectors as BowVocabulary::transform returns them (bow_voc.h:94-131) -> (off uint32[n + 1],
+    words uint32[total], values float64[total]): every image names `words_per_image` distinct words
+    (fewer when draws collide) in no particular order, values positive and L1-normalised the way the
+    reference does it (weights summed in order, each divided by the sum).  Image i takes
+    `share_frac` of its words from a pool that moves with i (images closer than `window` overlap
+    much, all images overlap a little through the frequent words), the rest uniformly."""
+    off = np.zeros(n_img + 1, dtype=np.uint32)
+    words, values = [], []
+    m = int(words_per_image)
+    n_shared = int(m * share_frac)
+    pool = max(2 * m, 16)
+    r = u64(seed, 0x7000, (n_img, m))
+    wt = 0.5 + 10.0 * _unit(seed, 0x71, (n_img, m))
+    for i in range(n_img):
+        near = (np.uint64(i // max(window, 1) * (pool // 2)) + r[i, :n_shared] % np.uint64(pool)) % np.uint64(n_words)
+        far = (r[i, n_shared:] >> np.uint64(20)) % np.uint64(n_words)
+        w = np.concatenate([near, far]).astype(np.uint32)
+        _, first = np.unique(w, return_index=True)
+        keep = np.sort(first)  # order of first appearance
+        w, x = w[keep], wt[i, keep]
+        total = 0.0
+        for v in x.tolist():
+            total += v
+        words.append(w)
+        values.append(x / total)
+        off[i + 1] = off[i] + len(w)
+    return off, np.concatenate(words) if words else np.zeros(0, np.uint32), \
+        np.concatenate(values) if values else np.zeros(0, np.float64)
