@@ -581,6 +581,45 @@ def main():
             "latency_ms_host_to_host": blat * 1e3, "cpu_port_ms_1_thread": bcpu * 1e3,
             "bit_exact_vs_cpu": bool(np.array_equal(bw[0], cw[0]) and np.array_equal(bw[1], cw[1])),
             "note": "parity unpinned: the reference's vocabulary file is not in its checkout; synthetic tree"}
+        # next row N4, database half (pinned by the reference's bow_db.json / bow_dist.cereal): the pair
+        # selection of match_bow (sfm.cpp:1366-1392) for 5000 images x ~1000 words of a 10^6-word
+        # vocabulary, 25 candidates each; the CPU loop (oracle, one thread) on the first 1000 images
+        bcsr = synth.bow_vectors(5000, 1000000, 1000, a.seed + 9, window=8)
+        bframes = np.arange(5000) // 2
+        for _ in range(2):
+            t = time.perf_counter()
+            m.bowdb_upload(bcsr)
+            t_up = time.perf_counter() - t
+            t = time.perf_counter()
+            bpairs = m.bow_select_pairs(bframes, 25)
+            t_sel = time.perf_counter() - t
+        bq = [list(zip(bcsr[1][bcsr[0][i]:bcsr[0][i + 1]].tolist(), bcsr[2][bcsr[0][i]:bcsr[0][i + 1]].tolist())) for i in (4999,)]
+        t = time.perf_counter()
+        for _ in range(20):
+            bres = m.bowdb_query(bq, 25)
+        t_q = (time.perf_counter() - t) / 20
+        cut = int(bcsr[0][1000])
+        t = time.perf_counter()
+        cpairs, cscore = _ob.match_bow_pairs([(int(f), i % 2) for i, f in enumerate(bframes[:1000])], bcsr[0][:1001],
+                                             bcsr[1][:cut], bcsr[2][:cut], 25)
+        t_cpu = time.perf_counter() - t
+        gsub = bpairs[bpairs[:, 0] < 1000]
+        odb = _ob.BowDb()
+        for i in range(5000):
+            odb.insert((i, 0), bcsr[1][bcsr[0][i]:bcsr[0][i + 1]], bcsr[2][bcsr[0][i]:bcsr[0][i + 1]])
+        t = time.perf_counter()
+        ofc, osc = odb.query(bcsr[1][bcsr[0][4999]:], bcsr[2][bcsr[0][4999]:], 25)
+        t_cq = time.perf_counter() - t
+        extra["bow_database_5000img_1000words"] = {
+            "select_pairs_ms": t_sel * 1e3, "upload_ms": t_up * 1e3, "pairs": int(len(bpairs)),
+            "single_query_ms_host_to_host": t_q * 1e3, "cpu_single_query_ms_1_thread": t_cq * 1e3,
+            "cpu_select_pairs_ms_1_thread_first_1000_images": t_cpu * 1e3,
+            "pairs_of_first_1000_images_gpu_cpu": [int(len(gsub)), int(len(cpairs))],
+            "pairs_of_first_1000_images_in_both": int(len(set(map(tuple, gsub.tolist())) & set(map(tuple, cpairs.tolist())))),
+            "single_query_scores_bit_exact_vs_cpu": bool(np.array_equal(np.sort(bres[0][1]), np.sort(osc))),
+            "note": "BowDatabase::query for every image against the images before it (query-then-insert), one wave "
+                    "per query; scores carry the reference's bits, equal scores are ordered by image index where the "
+                    "reference leaves the order open; the CPU loop's cost grows with the square of the image count"}
         # config 3 shape: 164 images (82 stereo frames) of 1200-1500 descriptors, the 13284
         # non-stereo pairs of sfm.cpp:1285-1290 in one batch
         sz = np.random.default_rng(3).integers(1200, 1501, size=164)

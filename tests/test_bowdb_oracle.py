@@ -108,3 +108,20 @@ def test_transform_accumulation_against_bow_res2():
     assert max(abs(want[w] - v) for w, v in bow) < 1e-10
     first = [int(w) for w, x in zip(G["kd0_word"], G["kd0_weight"]) if x != 0]
     assert list(dict.fromkeys(first)) == words  # order of first appearance, zero weights skipped
+
+
+def test_vectors_of_a_whole_database_equal_the_loop():
+    """matcher.bow_vectors_of_images (numpy, every image at once) against matcher.bow_vector (the
+    loop of bow_voc.h:107-130), bit for bit; images without features or with zero weights only."""
+    rng = np.random.default_rng(3)
+    off = np.array([0, 0, 400, 401, 1300, 1300, 1310], np.int64)
+    words = rng.integers(0, 120, 1310).astype(np.uint32)
+    weights = rng.random(1310) * 7
+    weights[rng.random(1310) < 0.1] = 0
+    weights[1300:] = 0
+    vo, vw, vv = vsm.matcher.bow_vectors_of_images(words, weights, off)
+    assert vo[0] == 0 and len(vo) == 7 and vo[-1] == len(vw) == len(vv)
+    for i in range(6):
+        want = vsm.matcher.bow_vector(words[off[i]:off[i + 1]], weights[off[i]:off[i + 1]])
+        assert [w for w, _ in want] == vw[vo[i]:vo[i + 1]].tolist()
+        assert [v for _, v in want] == vv[vo[i]:vo[i + 1]].tolist()

@@ -207,3 +207,31 @@ def test_cpp_shim_database(tmp_path):
     for q, rows in got.items():
         fc, sc = db.query(*vecs[q], k)
         assert rows == [(int(f), int(c), float(s)) for (f, c), s in zip(fc, sc)]
+
+
+def test_match_bow_end_to_end():
+    """sfm_pairs.match_bow = the reference's match_bow (sfm.cpp:1357-1423) up to the RANSAC step: words
+    (GPU) -> BoW vectors (host) -> candidate pairs (GPU) -> matches (GPU), each stage against the oracle.
+    The vocabulary is synthetic (the reference's file is missing: that stage is parity unpinned)."""
+    sfm = importlib.import_module("visual-slam_amd.sfm_pairs")
+    n, k = 60, 6
+    db, off = synth.sfm_database(n, 260, seed=8, share_frac=0.5, window=4)
+    voc = synth.vocabulary(8, 3, 17)
+    frame = np.arange(n) // 2
+    o = binding.port()
+    with vsm.Matcher(0) as m:
+        m.voc_upload(voc)
+        pairs, out_off, matches = sfm.match_bow(m, db, off, frame, k, 70, 1.2, max_features_per_call=5000)
+        w, x = o.bow_words(db, voc)
+        vec = [vsm.matcher.bow_vector(w[off[i]:off[i + 1]], x[off[i]:off[i + 1]]) for i in range(n)]
+        res = m.bowdb_query(vec, k, db_limit=np.arange(n))  # the database as match_bow left it: the same vectors
+    vecs = [(np.array([a for a, _ in v], np.uint32), np.array([b for _, b in v])) for v in vec]
+    want = []
+    for i, (idx, score) in enumerate(res):
+        check_query(oracle_db(vecs, i), i, vecs[i], k, idx, score)
+        want += [(i, int(j)) for j in idx if frame[i] != frame[j]]
+    assert [tuple(p) for p in pairs.tolist()] == want and len(want) > 150
+    assert int(out_off[-1]) == len(matches) > 1000
+    for p, (i, j) in enumerate(want):
+        assert np.array_equal(matches[int(out_off[p]):int(out_off[p + 1])],
+                              o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)), (i, j)

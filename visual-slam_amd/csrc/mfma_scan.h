@@ -181,6 +181,15 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         f32x16 Dn = zero;
+        auto expand_next = [&]() {  // the next step's train rows; the step after goes in flight
+          An[0] = expand_bits_r(wn.x, m88, c22);
+          An[1] = expand_bits_r(wn.y, m88, c22);
+          An[2] = expand_bits_r(wn.z, m88, c22);
+          An[3] = expand_bits_r(wn.w, m88, c22);
+          wn = row(off);
+          off += 1024u;
+        };
+        if (NB == 1) expand_next();  // a one-block tile: its only block needs them now
         if (b + 1 < NB) {
 #pragma unroll
           for (int m = 0; m < 4; m++) Dn = mfma_step(A[m], B[b + 1][m], Dn);
@@ -188,14 +197,7 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
 #pragma unroll
           for (int m = 0; m < 4; m++) Dn = mfma_step(An[m], B[0][m], Dn);
         }
-        if (b == (NB >= 2 ? NB - 2 : 0)) {
-          An[0] = expand_bits_r(wn.x, m88, c22);
-          An[1] = expand_bits_r(wn.y, m88, c22);
-          An[2] = expand_bits_r(wn.z, m88, c22);
-          An[3] = expand_bits_r(wn.w, m88, c22);
-          wn = row(off);
-          off += 1024u;
-        }
+        if (NB >= 2 && b == NB - 2) expand_next();  // one block early, behind the MFMAs of the last block
         asm volatile("" : "+v"(Dn));  // keeps the MFMAs above the minimum tree (and their result in VGPRs)
         int x[16];
 #pragma unroll
@@ -268,6 +270,23 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
   }
 }
 
+// The grid counts queries in units of 64, a tile in blocks of 32: when the last block of a job's last
+// tile holds no query at all (2000 queries: the eighth 256-query tile has 208, six and a half blocks)
+// the tile runs with one block less -- 1/64 of the MFMA work of a 2000-query job.
+template <int NB>
+__device__ __forceinline__ void mfma_scan_tile_fit(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
+                                                     const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
+                                                     u32 split_stride, uint2* __restrict__ scratch,
+                                                     const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
+#ifndef VSM_TILE_FIT
+#define VSM_TILE_FIT 1  // 0: A/B builds only
+#endif
+  if (VSM_TILE_FIT && NB > 1 && q0 + (NB - 1) * 32 >= job.nq)
+    mfma_scan_tile<(NB > 1 ? NB - 1 : 1)>(qbase, tbase, job, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
+  else
+    mfma_scan_tile<NB>(qbase, tbase, job, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
+}
+
 // WAVES == 1: one-wave workgroups, the grid of scan_kernel_adaptive<*, 1, *>: tiles of 32 * NBMAX
 // queries and remainder tiles of half and a quarter of that, grouped or job-minor block order
 // (see there).  WAVES == 4: the grid of scan_kernel (4-wave workgroups, job-minor), used with
@@ -296,20 +315,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
   constexpr u32 RMAX = NBMAX / 2;  // tiles are counted in units of 64 queries, as adaptive_tiles does
   const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
   if (t < full) {
-    mfma_scan_tile<NBMAX>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+    mfma_scan_tile_fit<NBMAX>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
     return;
   }
   u32 k = t - full, q0 = full * 64 * RMAX;
   if (RMAX > 2 && (rem & 2)) {
     if (k == 0) {
-      mfma_scan_tile<4>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+      mfma_scan_tile_fit<4>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
       return;
     }
     k--;
     q0 += 128;
   }
   if ((rem & 1) && k == 0)
-    mfma_scan_tile<2>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+    mfma_scan_tile_fit<2>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
 }
 
 }  // namespace vsm

@@ -518,6 +518,36 @@ def bow_vector(words, weights):
     return [(w, acc[w] / total) for w in order]
 
 
+def bow_vectors_of_images(words, weights, offsets):
+    """bow_voc.h:107-130 for every image of a database at once: features offsets[i] .. offsets[i+1]
+    belong to image i.  -> (vec_off uint32[n + 1], vec_words uint32[*], vec_values float64[*]), the
+    `vsm_bowdb_upload` layout.  Same additions in the same order as `bow_vector` (np.add.at and
+    np.cumsum add one element after the other), so the same bits."""
+    words = np.asarray(words, dtype=np.uint32)
+    weights = np.asarray(weights, dtype=np.float64)
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    vec_off = np.zeros(n + 1, dtype=np.uint32)
+    out_w, out_v = [], []
+    for i in range(n):
+        w, x = words[offsets[i]:offsets[i + 1]], weights[offsets[i]:offsets[i + 1]]
+        keep = x != 0  # bow_voc.h:114
+        w, x = w[keep], x[keep]
+        if len(w):
+            uniq, first, inv = np.unique(w, return_index=True, return_inverse=True)
+            order = np.argsort(first, kind="stable")  # words in order of first appearance
+            slot = np.empty(len(uniq), dtype=np.int64)
+            slot[order] = np.arange(len(uniq))
+            acc = np.zeros(len(uniq), dtype=np.float64)
+            np.add.at(acc, slot[inv], x)
+            total = np.cumsum(x)[-1]
+            out_w.append(uniq[order].astype(np.uint32))
+            out_v.append(acc / total)
+        vec_off[i + 1] = vec_off[i] + (len(out_w[-1]) if len(w) else 0)
+    return vec_off, (np.concatenate(out_w) if out_w else np.zeros(0, np.uint32)), \
+        (np.concatenate(out_v) if out_v else np.zeros(0, np.float64))
+
+
 _default = threading.local()
 
 

@@ -185,3 +185,27 @@ def nn2_sharded(query, train, group=None, device="cpu", nn2_fn=None):
     dist.all_gather(parts, mine, group=group)
     full = torch.cat(parts, dim=1)[:, :nq].cpu().numpy()
     return full[0], full[1], full[2]
+
+
+def match_bow(matcher, desc, offsets, frame_ids, num_bow_candidates: int = 25, threshold: int = 70,
+              dist_2_best: float = 1.2, max_features_per_call: int = 1 << 23):
+    """`match_bow` of the reference (src/sfm.cpp:1357-1423) on one GPU, for a descriptor database in
+    the `vsm_db_upload` layout and a vocabulary already uploaded (`matcher.voc_upload`): every
+    descriptor's word (bow_voc.h:57-92, GPU), every image's BoW vector (bow_voc.h:107-130, host: a few
+    hundred ordered double additions per image), the candidate pairs (query-then-insert over a BoW
+    database, sfm.cpp:1373-1392, GPU), and matchDescriptors on those pairs (sfm.cpp:1409-1411, GPU).
+    -> (pairs uint32[n, 2], out_offsets int64[n + 1], matches int32[total, 2]).
+    The caller's next step (findInliersRansac, sfm.cpp:1413-1418) is outside this path."""
+    from .matcher import as_descriptors, bow_vectors_of_images
+    desc = as_descriptors(desc)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    words = np.zeros(len(desc), dtype=np.uint32)
+    weights = np.zeros(len(desc), dtype=np.float64)
+    for a in range(0, len(desc), max_features_per_call):
+        words[a:a + max_features_per_call], weights[a:a + max_features_per_call] = \
+            matcher.bow_words(desc[a:a + max_features_per_call])
+    matcher.bowdb_upload(bow_vectors_of_images(words, weights, offsets))
+    pairs = matcher.bow_select_pairs(frame_ids, num_bow_candidates)
+    matcher.db_upload(desc, offsets)
+    out_offsets, matches = matcher.match_pairs(pairs, threshold, dist_2_best)
+    return pairs, out_offsets, matches
