@@ -498,13 +498,13 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     if (prune) {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, acc));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1, (const u32*)acc.mask, desc,
-                         sh.mfma ? 1u : 0u);
+                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1, (const u32*)acc.mask);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
       hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
-                         (const u32*)c->flist.p, stride, prm, d_counts, desc, shb.mfma ? 1u : 0u);
+                         (const u32*)c->flist.p, stride, prm, d_counts, desc,
+                         (sh.mfma ? 1u : 0u) | (shb.mfma ? 2u : 0u));
     } else {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
       if (sh.splits > 1 || sh.mfma) {

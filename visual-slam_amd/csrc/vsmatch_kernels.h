@@ -347,10 +347,20 @@ __global__ __launch_bounds__(256) void merge_splits_kernel(uint2* __restrict__ s
 // descriptor of the job's train range, `per` = rows per train split (= nt when unsplit).  Called
 // by the consumers only for results the accept test would otherwise pass (a few per image pair)
 // and by the raw 2-NN output for every query.  Idempotent, and harmless on an exact result.
-// Cost on a DENSE batch (real-like database: 700 accepted rows per image pair): 15 rows x 32 B per
-// result = 7.7 GB per 19900 pairs out of L2, 1.05 ms of nominate_kernel's 1.3 ms at ~7 TB/s -- bound
-// by L2 bandwidth, not by the loads' latency or line count (sixteen lanes per result with four
-// results in flight per group: the same 1.3 ms).
+// Cost on a DENSE batch (real-like database: 700 listed rows per image pair): four 128-byte lines per
+// result, 7.2 GB per 19900 pairs when every listed row is refined (1.05 ms of nominate_kernel's 1.3).
+// The lines come from beyond L2: the forward scan of the whole launch (4 GB streamed) lies between a
+// job's scan and its consumer kernels, so its train image has left the 4 MB L2s long before.  What
+// helped: refining a forward result only after the cross-check (count_list_kernel), when a third of
+// the listed rows are gone -- real-like batch 10.5 -> 9.7 ms (A/B on one box).  Tried without gain
+// (tools/prof_real_like*.sh, round 2):
+//  * sixteen lanes per result, four results in flight per group: the same 1.3 ms;
+//  * eight lanes per result, each loading one 16-byte piece of a 128-byte chunk (8 lines per load
+//    instruction instead of 64), four results per team in flight: nominate 1.4, count_list 2.1 ms --
+//    the line count is the same, so the L1's lookup rate was not the limit;
+//  * a second instantiation for jobs listing >= nt / 8 rows that copies the train image into LDS
+//    first (64 KB per job instead of 350 KB from HBM): nominate 1.2, count_list 0.9 ms -- 20 bank
+//    conflict cycles per ds_read_b128 (64 lanes, random 32-byte rows) and two workgroups per CU.
 __device__ __forceinline__ u32 refine_second(const u32x4* __restrict__ q, const u32x4* __restrict__ tr, u32 nt,
                                              u32 per, uint2 v) {
   const u32 d = v.x >> IDX_BITS, idx = v.x & IDX_MASK;
@@ -688,9 +698,10 @@ __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
 //  1. the forward-accepted rows i, ascending, go to flist[p*stride ...) -- from the accept bits the
 //     matrix-core forward scan left (mfma_scan.h store_accept_mask: 4 bytes per 32 rows instead
 //     of every 8-byte result) or, after a popcount scan, from the results themselves;
-//  2. after a matrix-core scan (`refine`) each listed row's second best is made exact
-//     (refine_second) and the rows that no longer pass are dropped from the list;
-//  3. the columns best1[i] of the listed rows are marked in an LDS bitmap, compacted ascending
+//     after a matrix-core scan "accepted" is by the scan's upper bound of the second best, which can
+//     only list too many rows, never too few: count_list_kernel makes the second best exact for the
+//     rows that survive the cross-check and drops those that fail then;
+//  2. the columns best1[i] of the listed rows are marked in an LDS bitmap, compacted ascending
 //     into qlist[p*stride ...) and the backward job is rewritten to scan just that list.
 // jobs[p].pad1 = number of listed rows: count_list_kernel / fill_list_kernel then read those few
 // rows instead of every row's result.  Exact: every backward result the consumer kernels read is
@@ -703,12 +714,11 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
                                                        u32* __restrict__ qlist,
                                                        u32* __restrict__ flist,
                                                        u64* __restrict__ comps,
-                                                       const u32* __restrict__ accmask,
-                                                       const u32x4* __restrict__ desc, u32 refine) {
+                                                       const u32* __restrict__ accmask) {
   __shared__ uint16_t lut[260];
   __shared__ u32 bitmap[NOMINATE_MAX_STRIDE / 32];
   __shared__ u32 wave_cnt[4];
-  // the first NOMINATE_LDS_LIST listed rows also stay in LDS between steps 1 and 2: reading them
+  // the first NOMINATE_LDS_LIST listed rows are also kept in LDS between steps 1 and 2: reading them
   // back from global memory right after writing them cost a round trip per workgroup (215 us per
   // 32768 sparse pairs against 80 us)
   __shared__ u32 slist[NOMINATE_LDS_LIST];
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
         const u32 i = w * 32 + (u32)__builtin_ctz(bits);
         bits &= bits - 1;
         if (pos < NOMINATE_LDS_LIST) slist[pos] = i;
-        else list[pos] = i;
+        list[pos] = i;
         pos++;
       }
     }
@@ -766,34 +776,16 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
       acc = place(hit ? 1u : 0u, acc, pos);
       if (hit) {
         if (pos < NOMINATE_LDS_LIST) slist[pos] = i;
-        else list[pos] = i;
+        list[pos] = i;
       }
     }
   }
   __syncthreads();  // the list is read below by other threads
-  // refine the listed rows, drop those that fail now (in place: a chunk writes at or below where
-  // it read, after every thread has read), mark the columns of the others
-  u32 kept = 0;
-  for (u32 base = 0; base < acc; base += 256) {
-    const u32 k = base + threadIdx.x;
-    u32 i = 0, j = 0;
-    bool keep = false;
-    if (k < acc) {
-      i = k < NOMINATE_LDS_LIST ? slist[k] : list[k];
-      uint2 v = scratch[f.out_off + i];
-      j = v.x & IDX_MASK;
-      keep = true;
-      if (refine) {
-        const u32 s = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, v);
-        keep = s >= (u32)lut[v.x >> IDX_BITS];
-      }
-    }
-    u32 pos;
-    kept = place(keep ? 1u : 0u, kept, pos);  // its barriers order this chunk's reads before the writes
-    if (keep) {
-      list[pos] = i;
-      atomicOr(&bitmap[j >> 5], 1u << (j & 31));
-    }
+  // mark the columns of the listed rows
+  for (u32 k = threadIdx.x; k < acc; k += 256) {
+    const u32 i = k < NOMINATE_LDS_LIST ? slist[k] : list[k];
+    const u32 j = scratch[f.out_off + i].x & IDX_MASK;
+    atomicOr(&bitmap[j >> 5], 1u << (j & 31));
   }
   __syncthreads();
   u32 done = 0;
@@ -808,7 +800,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
     }
   }
   if (threadIdx.x == 0) {
-    f.pad1 = kept;
+    f.pad1 = acc;
     jobs[p] = f;
     b.nq = done;
     b.qlist_off = p * stride;
@@ -841,15 +833,27 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
   u32 mine = 0;
   for (u32 k = threadIdx.x; k < f.pad1; k += blockDim.x) {
     u32 j;
-    bool hit = cross_check_listed(scratch, f, b, list[k], lut, prm.threshold, j);
-    if (hit && refine) {
-      // backward result of the matrix-core scan: exact second best before it counts.  Written
-      // back, so that fill_list_kernel sees the finished result; column j has this one writer
-      // (only the row it points back at gets here).
-      const uint2 v = scratch[b.out_off + j];
-      const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, v);
-      if (s2 != min(v.y >> IDX_BITS, 256u)) scratch[b.out_off + j].y = s2 << IDX_BITS;
-      hit = s2 >= (u32)lut[v.x >> IDX_BITS];
+    const u32 i = list[k];
+    bool hit = cross_check_listed(scratch, f, b, i, lut, prm.threshold, j);
+    if (hit && refine) {  // bit 0: forward results come from the matrix-core scan, bit 1: backward ones
+      // Results of the matrix-core scan: exact second bests before the pair counts -- the forward
+      // one of row i (nominate_kernel lists rows by the scan's upper bound and leaves it to this
+      // point, where only the rows that survive the cross-check are left: a third fewer on a dense
+      // batch; an upper bound can only list too many rows, never too few), then the backward
+      // one of column j.  Written back, so that fill_list_kernel sees finished results; each has
+      // this one writer (row i is this thread's, column j points back at it).
+      if (refine & 1u) {
+        const uint2 vf = scratch[f.out_off + i];
+        const u32 sf = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, vf);
+        if (sf != min(vf.y >> IDX_BITS, 256u)) scratch[f.out_off + i].y = sf << IDX_BITS;
+        hit = sf >= (u32)lut[vf.x >> IDX_BITS];
+      }
+      if (hit && (refine & 2u)) {
+        const uint2 v = scratch[b.out_off + j];
+        const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, v);
+        if (s2 != min(v.y >> IDX_BITS, 256u)) scratch[b.out_off + j].y = s2 << IDX_BITS;
+        hit = s2 >= (u32)lut[v.x >> IDX_BITS];
+      }
     }
     mine += hit ? 1u : 0u;
   }
@@ -879,7 +883,9 @@ __global__ __launch_bounds__(256) void fill_list_kernel(const Job* __restrict__ 
     bool hit = false;
     if (k < f.pad1) {
       i = list[k];
-      hit = cross_check_listed(scratch, f, b, i, lut, prm.threshold, j);
+      u32 jf;
+      hit = accepted(scratch[f.out_off + i], lut, prm.threshold, jf) &&  // finished by count_list_kernel
+            cross_check_listed(scratch, f, b, i, lut, prm.threshold, j);
     }
     const u64 m = __ballot(hit);
     if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
