@@ -470,6 +470,22 @@ def main():
                                      "matches": int(len(res)), "reference_equivalent_gcomps": 2 * 1500 * 1500 / lat / 1e9,
                                      "note": "host pointers in, host list out, PCIe inclusive: 4 kernels in one queue (staging from mapped host memory, "
                                              "scan, merge + refine, emit into mapped host memory), the host polls a flag"}
+        # the batched call through its host-pointer form (vsm_match_pairs: pair list up, offsets and
+        # lists down over PCIe) on the first timed step's 32768 pairs -- the PCIe-inclusive rate,
+        # never `value`
+        hp = step_pairs[min(a.warmup, len(step_pairs) - 1)]
+        m.set_profiling(False)
+        for _ in range(2):
+            hoffs, hlists = m.match_pairs(hp, a.threshold, a.ratio, cap=64 * len(hp))
+        t = time.perf_counter()
+        for _ in range(5):
+            hoffs, hlists = m.match_pairs(hp, a.threshold, a.ratio, cap=64 * len(hp))
+        t_host = (time.perf_counter() - t) / 5
+        extra["batched_host_pointer_api"] = {
+            "pairs": int(len(hp)), "ms_per_call": t_host * 1e3, "pairs_per_s": len(hp) / t_host,
+            "matches": int(len(hlists)),
+            "note": "vsm_match_pairs: 8 B per pair host to device, 8 B per pair + 8 B per match back, PCIe inclusive; "
+                    "the database is resident (vsm_db_upload / vsm_db_attach once)"}
         # next row N1: one odometry frame of find_matches_landmarks
         # (vo_utils.h:95-187, odometry.cpp:832): 1500 keypoints x 2500 projected landmarks,
         # radius 20 px (odometry.cpp:177), host pointers in/out; CPU = the C oracle, 1 thread
