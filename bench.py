@@ -279,6 +279,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Set-up, before the W warm-up steps: the library's work buffers are allocated by its first call,
+    # and the clock of an idle MI355X takes about five launches of this kernel to settle (same cycle
+    # count, 1.66 -> 1.95 GHz: profiles/r02/README.md).  Weak mode only (a strong step is seconds long).
+    settle = 0 if a.strong else 5
+    for _ in range(settle):
+        run(0)
     gathered = None
     for s in range(a.warmup):
         try:
@@ -399,7 +405,8 @@ def main():
         "pairs_per_s": pairs_all / dt, "reference_equivalent_gcomps": comps_all / dt / 1e9,
         "matches_per_step": matches_all / a.steps,
         "roofline": roofline,
-        "setup": {"db_generate_s": t_gen, "db_broadcast_or_upload_s": t_bc, "gather_last_step_ms": gather_ms,
+        "setup": {"db_generate_s": t_gen, "db_broadcast_or_upload_s": t_bc, "clock_settle_calls_before_warmup": settle,
+                  "gather_last_step_ms": gather_ms,
                   "gathered_lists_consistent": gathered_ok,
                   "gather": ("inside every timed step" if a.strong and multi else
                              "timed apart from the steps" if multi else "single rank: nothing to gather")},
