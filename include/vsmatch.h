@@ -127,7 +127,11 @@ int vsm_nn2_device(vsm_ctx* ctx, const void* d_query, size_t nq, const void* d_t
  * flattened: image i owns descriptors offsets[i] .. offsets[i+1]-1 of `desc`.
  * upload copies host memory into HBM; attach borrows a DEVICE pointer (e.g. a
  * buffer an RCCL broadcast has just filled) that must outlive its use.
- * offsets is a host array of n_img + 1 entries either way.
+ * offsets is a host array of n_img + 1 entries either way.  Both calls read
+ * every descriptor once (a one-byte-per-descriptor table for the batched
+ * matcher is built from them): the contents of an attached buffer must be
+ * complete when vsm_db_attach is called (see "stream ordering" above) and stay
+ * unchanged while it is attached -- attach again after rewriting it.
  */
 int vsm_db_upload(vsm_ctx* ctx, const uint64_t* desc, const uint32_t* offsets, size_t n_img);
 int vsm_db_attach(vsm_ctx* ctx, const void* d_desc, const uint32_t* offsets, size_t n_img);

@@ -178,6 +178,51 @@ def test_second_best_next_to_the_best(m, gap):
             m.set_variant(0)
 
 
+def _flip(d, bits):
+    d = d.copy()
+    for k in bits:
+        d[k // 64] ^= np.uint64(1) << np.uint64(k % 64)
+    return d
+
+
+@pytest.mark.parametrize("d", [0, 5, 10, 25, 58])
+def test_group_table_certificate_at_its_boundary(m, d):
+    """The consumer kernels skip the refinement of a second best when the best row's group table
+    entry proves no group mate can matter (vsmatch_kernels.h second_certified: gmin[t] >=
+    min_second[d] + d).  The tight case of the triangle inequality: train row t' = t with a set A of g
+    bits flipped sits next to t (same group), the query is t with d of A's bits flipped, so that
+    dist(q, t') = g - d exactly; g around min_second[d] + d, where the certificate starts to hold and
+    the ratio test starts to pass.  Batched both ways (forward and backward results), against the oracle."""
+    rng = np.random.default_rng(300 + d)
+    need = int(np.ceil(1.2 * d - 1e-9))
+    base = cases.synth.random_descriptors(256, 77 + d, 3)
+    q, t = base[:96].copy(), cases.synth.random_descriptors(128, 78 + d, 4)
+    for k in range(48):
+        g = need + d + (k % 7) - 3          # gmin of the pair of rows: three below the bound to three above
+        if g <= d:
+            continue
+        a = rng.choice(256, size=g, replace=False)
+        row = 2 * k + (k % 2) * 32          # t' right behind t; some pairs straddle a 4-row chunk
+        row = min(row, 126)
+        t[row + 1] = _flip(t[row], a)
+        q[k] = _flip(t[row], a[:d])
+    o = binding.port()
+    want, want_t = o.match(q, t, 70, 1.2), o.match(t, q, 70, 1.2)
+    assert 8 < len(want) < 48 and 8 < len(want_t) < 48  # some pass, some fail, in both directions
+    db = np.concatenate([q, t])
+    off = np.array([0, len(q), len(q) + len(t)], np.uint32)
+    pairs = np.array([[0, 1], [1, 0]] * 1100, np.uint32)  # enough jobs for the pruned batched path
+    for variant in (0, TILE64 | 8, NO_PRUNE | 8):
+        m.set_variant(variant)
+        try:
+            m.db_upload(db, off)
+            offs, lists = m.match_pairs(pairs, 70, 1.2)
+            for k in (0, 1, 2198, 2199):
+                assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want if k % 2 == 0 else want_t), (hex(variant), d, k)
+        finally:
+            m.set_variant(0)
+
+
 def test_real_like_database_batched():
     """A database with the distance statistics of real ORB descriptors (unrelated descriptors
     126 +- 19 bits apart; duplicates, ties, crowded neighbourhoods): the batched matcher's lists

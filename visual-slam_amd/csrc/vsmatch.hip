@@ -140,6 +140,7 @@ struct vsm_ctx {
   const void* db = nullptr;
   DevBuf db_owned;
   DevBuf d_img_off;
+  DevBuf gmin;  // one byte per database descriptor (group_min_kernel), valid for `db`
   std::vector<u32> img_off;
   u32 max_n = 0;
   // per full-tile size rmax = 8, 4, 2, 1 (index 0..3): most adaptive tiles any image of the
@@ -488,6 +489,11 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   u32* d_counts = (u32*)c->counts.p;
   const u32x4* desc = (const u32x4*)d_desc;
   const u32 d_lim = accept_limit(prm);
+#ifdef VSM_AB_NO_GROUP_TABLE  // A/B builds only
+  const uint8_t* gmin = nullptr;
+#else
+  const uint8_t* gmin = own_db ? (const uint8_t*)c->gmin.p : nullptr;  // the table belongs to the context's database
+#endif
 
   for (u64 first = 0; first < n_pairs; first += chunk) {
     const u32 n = (u32)std::min<u64>(chunk, n_pairs - first);
@@ -504,7 +510,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                           (const u32*)c->qlist.p, d_lim));
       hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
                          (const u32*)c->flist.p, stride, prm, d_counts, desc,
-                         (sh.mfma ? 1u : 0u) | (shb.mfma ? 2u : 0u));
+                         (sh.mfma ? 1u : 0u) | (shb.mfma ? 2u : 0u), gmin);
     } else {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
       if (sh.splits > 1 || sh.mfma) {
@@ -587,6 +593,16 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
     c->avg_tiles[ri] = n_img ? sum_tiles[ri] / (double)n_img : 0.0;
   }
   c->db = d_desc;
+  // the group table of the consumer kernels (vsmatch_kernels.h, group_min_kernel): reads every
+  // descriptor once, now
+  const size_t total = n_img ? offsets[n_img] : 0;
+  VSM_TRY(c->gmin.reserve(std::max<size_t>(total, 1)));
+  if (total) {
+    hipLaunchKernelGGL(group_min_kernel, dim3((u32)((total + 255) / 256)), dim3(256), 0, c->stream, (const u32x4*)d_desc,
+                       (const u32*)c->d_img_off.p, (u32)n_img, (u32)total, (uint8_t*)c->gmin.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   return VSM_OK;
 }
 
@@ -641,7 +657,7 @@ void vsm_destroy(vsm_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (DevBuf* b : {&c->db_owned, &c->d_img_off, &c->stage, &c->scratch, &c->jobs, &c->counts, &c->misc, &c->qlist, &c->flist, &c->accmask, &c->lut,
-                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc, &c->bowdb, &c->bowdb_work})
+                      &c->w_pairs, &c->w_offsets, &c->w_out, &c->image, &c->gftt, &c->voc, &c->bowdb, &c->bowdb_work, &c->gmin})
       b->release();
     c->pin.release();
     c->pin_image.release();

@@ -389,6 +389,51 @@ __device__ __forceinline__ u32 refine_second(const u32x4* __restrict__ q, const 
   return s;
 }
 
+// A certificate that refine_second cannot change an accept decision, so that the consumer kernels
+// of a dense batch need not read the fifteen group mates at all: gmin[t] = the smallest distance
+// from train row t to the other rows of ITS OWN group (rows of the same image; a fixed function of
+// the row number when the scan is unsplit: t0 = 0).  For a query q whose best row is t at distance d,
+// every group mate t' has dist(q, t') >= dist(t, t') - dist(q, t) >= gmin[t] - d (triangle
+// inequality of the Hamming distance), so if gmin[t] >= min_second[d] + d no group mate is closer
+// than min_second[d] and the exact second best passes the ratio test exactly when the scan's upper
+// bound did.  One byte per descriptor (clamped to 255: still a lower bound), computed once per
+// database (vsm_db_upload / vsm_db_attach); a job's table is 2 KB, so the lookups stay in L1 where
+// the refinement reads four 128-byte lines from beyond L2 per result.  Unrelated ORB descriptors
+// are ~126 bits apart and true matches a few dozen: the test settles ~95 % of the results of a
+// dense batch.  One thread per database row.
+__global__ __launch_bounds__(256) void group_min_kernel(const u32x4* __restrict__ desc, const u32* __restrict__ img_off,
+                                                        u32 n_img, u32 total, uint8_t* __restrict__ gmin) {
+  const u32 r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= total) return;
+  u32 lo = 0, hi = n_img;  // img_off[lo] <= r < img_off[hi]
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (img_off[mid] <= r) lo = mid;
+    else hi = mid;
+  }
+  const u32 o = img_off[lo], nt = img_off[lo + 1] - o, t = r - o;
+  const u32 b0 = (t & ~31u) + (t & 4u);  // refine_second's group with t0 = 0
+  const u32x4 qa = desc[2 * (size_t)r], qb = desc[2 * (size_t)r + 1];
+  u32 g = 255u;
+#pragma unroll
+  for (u32 k = 0; k < 16; k++) {
+    const u32 row = b0 + (k & 3u) + 8u * (k >> 2);
+    if (row < nt && row != t) {
+      const u32x4 ta = desc[2 * (size_t)(o + row)], tb = desc[2 * (size_t)(o + row) + 1];
+      g = min(g, (u32)(__popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                       __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w)));
+    }
+  }
+  gmin[r] = (uint8_t)g;
+}
+// true: the scan's upper bound of the second best already decides the accept test of result v
+// against train range t_off (see group_min_kernel); gmin may be null (no table: never certified)
+__device__ __forceinline__ bool second_certified(const uint8_t* __restrict__ gmin, u32 t_off, uint2 v,
+                                                 const uint16_t* lut) {
+  const u32 d = min(v.x >> IDX_BITS, 256u);
+  return gmin && (u32)gmin[t_off + (v.x & IDX_MASK)] >= (u32)lut[d] + d;
+}
+
 // keypoints.h:295-296: int(best) < threshold && dist_2_best*best <= second, plus
 // "best_match == -1 can never be emitted" (distance 256).
 __device__ __forceinline__ bool accepted(uint2 v, const uint16_t* lut, int threshold, u32& idx) {
@@ -823,7 +868,8 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
                                                          uint2* __restrict__ scratch,
                                                          const u32* __restrict__ flist, u32 stride,
                                                          AcceptParams prm, u32* __restrict__ counts,
-                                                         const u32x4* __restrict__ desc, u32 refine) {
+                                                         const u32x4* __restrict__ desc, u32 refine,
+                                                         const uint8_t* __restrict__ gmin) {
   __shared__ uint16_t lut[260];
   __shared__ u32 total;
   if (threadIdx.x == 0) total = 0;
@@ -842,17 +888,22 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
       // batch; an upper bound can only list too many rows, never too few), then the backward
       // one of column j.  Written back, so that fill_list_kernel sees finished results; each has
       // this one writer (row i is this thread's, column j points back at it).
+      // Most results are settled by the group table without reading a descriptor (second_certified).
       if (refine & 1u) {
         const uint2 vf = scratch[f.out_off + i];
-        const u32 sf = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, vf);
-        if (sf != min(vf.y >> IDX_BITS, 256u)) scratch[f.out_off + i].y = sf << IDX_BITS;
-        hit = sf >= (u32)lut[vf.x >> IDX_BITS];
+        if (!second_certified(gmin, f.t_off, vf, lut)) {
+          const u32 sf = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, vf);
+          if (sf != min(vf.y >> IDX_BITS, 256u)) scratch[f.out_off + i].y = sf << IDX_BITS;
+          hit = sf >= (u32)lut[vf.x >> IDX_BITS];
+        }
       }
       if (hit && (refine & 2u)) {
         const uint2 v = scratch[b.out_off + j];
-        const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, v);
-        if (s2 != min(v.y >> IDX_BITS, 256u)) scratch[b.out_off + j].y = s2 << IDX_BITS;
-        hit = s2 >= (u32)lut[v.x >> IDX_BITS];
+        if (!second_certified(gmin, b.t_off, v, lut)) {
+          const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, v);
+          if (s2 != min(v.y >> IDX_BITS, 256u)) scratch[b.out_off + j].y = s2 << IDX_BITS;
+          hit = s2 >= (u32)lut[v.x >> IDX_BITS];
+        }
       }
     }
     mine += hit ? 1u : 0u;
