@@ -270,7 +270,7 @@ int vsm_bow_words(vsm_ctx* ctx, const uint64_t* desc, size_t n, uint32_t* word_o
  * vsm_bowdb_upload replaces clear() + insert() (bow_db.h:49-61, 133) of images 0 .. n_img-1 IN THIS
  * ORDER: image i's BoW vector is (words[k], values[k]), k in [vec_off[i], vec_off[i+1]), as
  * BowVocabulary::transform returns it (a word at most once per image, values L1-normalised; word
- * ids < 2^26, values finite: VSM_ERR_INVALID otherwise).  An image is known by its index; the caller
+ * ids < 2^26, values finite, at most 2^24 images: VSM_ERR_INVALID otherwise).  An image is known by its index; the caller
  * keeps the FrameCamId of each.  HOST pointers, copied.
  *
  * vsm_bowdb_query replaces query() (bow_db.h:63-131) for n_q BoW vectors at once (same layout):

@@ -1591,7 +1591,21 @@ int vsm_bow_words(vsm_ctx* c, const uint64_t* desc, size_t n, uint32_t* word_out
 
 namespace {
 
+// The BoW database entry points build host-side tables whose size the caller's data decides: no
+// exception leaves the C ABI.
+template <class F>
+int no_throw(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(VSM_ERR_NOMEM, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(VSM_ERR_INVALID, "%s", e.what());
+  }
+}
+
 constexpr u32 BOWDB_MAX_WORD = 1u << 26;              // dense word table: 4 B per word id
+constexpr size_t BOWDB_MAX_IMAGES = (size_t)1 << 24;  // 64 lists of a query batch are counted in 32 bits
 constexpr size_t BOWDB_WORK_BUDGET = (size_t)256 << 20;  // score rows + candidate lists per launch
 
 int check_bow_vectors(const uint32_t* off, const uint32_t* words, const double* values, size_t n, const char* what) {
@@ -1666,8 +1680,9 @@ int bowdb_query_device(vsm_ctx* c, const u32* d_qoff, const u32* d_qwords, const
 extern "C" {
 
 int vsm_bowdb_upload(vsm_ctx* c, const uint32_t* vec_off, const uint32_t* words, const double* values, size_t n_img) {
+ return no_throw([&]() -> int {
   VSM_TRY(check_ctx(c));
-  if (n_img >= 0x7fffffffull) return fail(VSM_ERR_INVALID, "more than 2^31 images");
+  if (n_img > BOWDB_MAX_IMAGES) return fail(VSM_ERR_INVALID, "more than 2^24 images");
   VSM_TRY(check_bow_vectors(vec_off, words, values, n_img, "database"));
   const size_t total = vec_off[n_img];
   u32 max_word = 0;
@@ -1721,10 +1736,12 @@ int vsm_bowdb_upload(vsm_ctx* c, const uint32_t* vec_off, const uint32_t* words,
   c->bowdb_entries = total;
   c->bowdb_ready = true;
   return VSM_OK;
+ });
 }
 
 int vsm_bowdb_query(vsm_ctx* c, const uint32_t* q_off, const uint32_t* q_words, const double* q_values, size_t n_q,
                     const uint32_t* db_limit, size_t num_results, int32_t* out_idx, double* out_score, uint32_t* out_n) {
+ return no_throw([&]() -> int {
   VSM_TRY(check_ctx(c));
   if (n_q == 0) return VSM_OK;
   if (n_q >= 0x7fffffffull) return fail(VSM_ERR_INVALID, "more than 2^31 queries");
@@ -1751,10 +1768,12 @@ int vsm_bowdb_query(vsm_ctx* c, const uint32_t* q_off, const uint32_t* q_words, 
   const char* s = (const char*)c->stage.p;
   return bowdb_query_device(c, (const u32*)(s + o_off), (const u32*)(s + o_w), (const double*)(s + o_v), n_q,
                             db_limit ? (const u32*)(s + o_l) : nullptr, false, num_results, out_idx, out_score, out_n);
+ });
 }
 
 int vsm_bow_select_pairs(vsm_ctx* c, const int64_t* frame_id, size_t num_candidates, uint32_t (*pairs)[2], size_t cap,
                          size_t* n_pairs) {
+ return no_throw([&]() -> int {
   VSM_TRY(check_ctx(c));
   if (!n_pairs) return fail(VSM_ERR_INVALID, "null n_pairs");
   *n_pairs = 0;
@@ -1787,6 +1806,7 @@ int vsm_bow_select_pairs(vsm_ctx* c, const int64_t* frame_id, size_t num_candida
   *n_pairs = m;
   if (m > cap) return fail(VSM_ERR_CAPACITY, "%zu pairs, capacity %zu", m, cap);
   return VSM_OK;
+ });
 }
 
 }  // extern "C"
