@@ -324,16 +324,16 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   if (vr == 4) { s.adaptive = false; s.R = 4; }
   s.rmax = 4;
   if (s.adaptive) {
-    // Shorter waves for smaller batches: keep >= ~16 rounds of the 8192 resident waves so the
-    // tail of the launch stays small (tools/ragged_probe.py: at euroc_V1's image sizes 64-query
-    // tiles beat 256-query ones by 10 %).
-    const u64 ls = std::max<u64>(1, (max_nt + FKEY_MAX_SET - 1) / FKEY_MAX_SET);
-    auto waves_at = [&](int rmax) {
-      const int ri = rmax == 4 ? 1 : rmax == 2 ? 2 : 3;
-      const double per_job = avg_tiles ? avg_tiles[ri] : (double)adaptive_tiles(max_nq, (u32)rmax);
-      return (double)(jobs_per_launch ? jobs_per_launch : n_jobs) * per_job * (double)ls;
-    };
-    while (s.rmax > 1 && waves_at(s.rmax) < 131072.0) s.rmax /= 2;
+    // Full tiles of 256 queries (NB 8: the fewest operand expansions per MFMA) unless the database
+    // is RAGGED with small images (fewer than four 256-query tiles on average: euroc_V1's 117-1363
+    // corners): waves then differ 40-fold in length and 128-query tiles balance better.  Measured
+    // with the matrix-core scan (tools/ragged_probe.py, round 2; ms per batch at 256 / 128 / 64):
+    // euroc_V1 sizes 0.672 / 0.620 / 0.671, 164 images x 1200-1500 2.09 / 2.13 / 2.37, 200 x 478
+    // uniform 0.580 / 0.584 / 0.631, 96 x 2000 dense 2.52 / 2.57 / 2.72, 2048 pairs of 2000 x 2000
+    // 0.739 / 0.763 / 0.831.  (Round 1's rule -- smaller tiles until a launch has 131072 waves --
+    // was tuned on the popcount scan, whose waves cost the same per query at every tile size.)
+    (void)jobs_per_launch;
+    if (uniform_tiles && avg_tiles && !uniform_tiles[1] && avg_tiles[1] < 4.0) s.rmax = 2;
     const int force = (variant >> 28) & 0x7;
     if (force == 1 || force == 2 || force == 4) s.rmax = force;
   }
