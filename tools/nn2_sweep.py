@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sweeps (R, splits) of the scan kernel on the 1M x 1M one-direction config."""
+"""Sweeps (tile size, train splits) of the matrix-core scan on the 1M x 1M one-direction config."""
 import importlib, sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,14 +14,14 @@ o = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
 m = vsm.Matcher(0)
 m.set_profiling(True)
 ref = None
-for R in (4, 8):
-    for splits in (32, 48, 64, 128):
+for R, tile in ((8 | 0x40000000, 256), (8 | 0x20000000, 128)):
+    for splits in (0, 32, 40, 48, 64, 96, 128):
         m.set_variant(R | (splits << 8))
         best = 1e9
-        for rep in range(2):
+        for rep in range(3):
             m.nn2_device(q.data_ptr(), n, t.data_ptr(), n, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
             torch.cuda.synchronize()
             best = min(best, m.last_scan_stats()["scan_ms"])
         chk = (int(o[0].sum()), int(o[1].sum()), int(o[2].sum()))
         ref = ref or chk
-        print(f"R={R} splits={splits:3d}  {best:8.2f} ms  {n*n/best/1e6:8.1f} Gcomp/s  frac {n*n*16/best/1e9/39.3216:.3f}  {'ok' if chk == ref else 'MISMATCH'}", flush=True)
+        print(f"tile={tile} splits={splits:3d} (0 = the library's choice)  {best:8.2f} ms  {n*n/best/1e6:8.1f} Gcomp/s  frac {n*n*512/best/1e9/10066.3:.3f}  {'ok' if chk == ref else 'MISMATCH'}", flush=True)
