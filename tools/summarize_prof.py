@@ -31,9 +31,9 @@ with open(os.path.join(dst, "kernel_trace_stats.txt"), "w") as f:
     # `warmup` launches run at a lower clock: same cycle count, see pmc_counters.txt)
     durs = [(e - b) / 1e3 for b, e in q(os.path.join(src, "trace", "t_results.db"),
             f"select start, end from kernels where name like '%{DOMINANT}%' order by start")]
-    warm = int(line["warmup"])
+    warm = int(line["warmup"]) + int(line.get("setup", {}).get("clock_settle_calls_before_warmup", 0))  # every untimed launch
     timed_us = sum(durs[warm:]) / max(1, len(durs[warm:]))
-    f.write(f"# {DOMINANT}, every launch in us: {' '.join(f'{d:.1f}' for d in durs)}  (the first {warm} = warm-up, untimed by bench.py)\n")
+    f.write(f"# {DOMINANT}, every launch in us: {' '.join(f'{d:.1f}' for d in durs)}  (the first {warm} = set-up and warm-up, untimed by bench.py)\n")
     f.write(f"# average of the {len(durs) - warm} timed launches: {timed_us:.1f} us by the kernel trace; the bench line of this same "
             f"(profiled) run: avg_launch_ms {r['avg_launch_ms']:.3f} by HIP events, kernel {r['kernel_gcomps']:.0f} G comparisons/s, "
             f"roofline.frac {r['frac']:.4f}\n")
