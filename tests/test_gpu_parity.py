@@ -53,6 +53,7 @@ def test_pair_matches_recorded_reference(m, name):
 # 26 in the pruned backward pass, 27 in the latency shape; bits 28-30 adaptive full-tile size.
 POPCOUNT, INT_KEYS, NO_PRUNE, POP_BACK, POP_LAT = 0x2000000, 0x20000, 0x10000, 0x4000000, 0x8000000
 TILE256, TILE128, TILE64 = 0x40000000, 0x20000000, 0x10000000
+RUN2, RUN3, RUN4, RUN8 = 0x200000, 0x300000, 0x400000, 0x800000  # consecutive jobs per wave of the batched matrix-core scan
 
 
 @pytest.mark.parametrize("variant", [1, 4, 8, 0x0301, 0x0308, 0x1708, 0x4008, TILE256 | 8, TILE128 | 8, TILE64 | 8, TILE128 | 0x0208,
@@ -162,7 +163,7 @@ def test_second_best_next_to_the_best(m, gap):
     off = np.array([0, len(q), len(q) + len(t)], np.uint32)
     db = np.concatenate([q, t])
     pairs = np.array([[0, 1], [1, 0]] * 1100, np.uint32)  # enough jobs for the adaptive regime
-    for variant in (0, 1, 8, TILE64 | 8, 0x0308, 0x0301, NO_PRUNE | 8, POPCOUNT | 8):
+    for variant in (0, 1, 8, TILE64 | 8, 0x0308, 0x0301, NO_PRUNE | 8, POPCOUNT | 8, RUN3 | TILE256 | 8, RUN8 | NO_PRUNE | TILE256 | 8):
         m.set_variant(variant)
         try:
             assert np.array_equal(m.match(q, t, 70, 1.2), want), (hex(variant), gap)
@@ -212,7 +213,7 @@ def test_group_table_certificate_at_its_boundary(m, d):
     db = np.concatenate([q, t])
     off = np.array([0, len(q), len(q) + len(t)], np.uint32)
     pairs = np.array([[0, 1], [1, 0]] * 1100, np.uint32)  # enough jobs for the pruned batched path
-    for variant in (0, TILE64 | 8, NO_PRUNE | 8):
+    for variant in (0, TILE64 | 8, NO_PRUNE | 8, RUN4 | TILE256 | 8):
         m.set_variant(variant)
         try:
             m.db_upload(db, off)
@@ -233,7 +234,7 @@ def test_real_like_database_batched():
         mm.db_upload(db, off)
         want = [binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2) for i, j in pairs.tolist()]
         assert sum(len(w) for w in want) > 10000
-        for variant in (0, NO_PRUNE, POPCOUNT, POP_BACK, TILE64, 0x0200, 1):
+        for variant in (0, NO_PRUNE, POPCOUNT, POP_BACK, TILE64, 0x0200, 1, RUN2 | TILE256, RUN3 | TILE256, RUN8 | TILE256, RUN4 | NO_PRUNE | TILE256):
             mm.set_variant(variant)
             offs, out = mm.match_pairs(pairs, 70, 1.2)
             for k, w in enumerate(want):
@@ -455,8 +456,9 @@ def test_adaptive_tiles_on_ragged_database(m):
     offs, lists = m.match_pairs(pairs, 70, 1.2)
     # forced full-tile sizes 256 / 128 / 64 on the matrix cores and with the popcount scan (float and
     # integer keys), no pruning, popcount backward pass only
+    # runs of 2 / 3 / 8 consecutive jobs per wave (ragged images: a run ends where the query image changes)
     for variant in (TILE256, TILE128, TILE64, POPCOUNT | TILE256, POPCOUNT | TILE128, POPCOUNT | INT_KEYS | TILE64,
-                    NO_PRUNE, POP_BACK):
+                    NO_PRUNE, POP_BACK, RUN2 | TILE256, RUN3 | TILE256, RUN8 | TILE256, RUN8 | NO_PRUNE | TILE256):
         m.set_variant(variant)
         try:
             offs_v, lists_v = m.match_pairs(pairs, 70, 1.2)

@@ -152,12 +152,12 @@ int main(int argc, char** argv) {
       if (v.fmt == 44) {  // tiles of a job in one workgroup (one CU: they share its L1), job-minor order
         const dim3 g4(n_jobs * ((tiles + 3) / 4)), b4(256);
 #define ARGS4 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, 0u, d_lim
-        if (v.nb == 8) mfma_scan_kernel<8, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr});
-        else mfma_scan_kernel<4, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr});
+        if (v.nb == 8) mfma_scan_kernel<8, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
+        else mfma_scan_kernel<4, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
       } else
-      if (v.nb == 8) mfma_scan_kernel<8, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
-      else if (v.nb == 4) mfma_scan_kernel<4, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
-      else mfma_scan_kernel<2, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr});
+      if (v.nb == 8) mfma_scan_kernel<8, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+      else if (v.nb == 4) mfma_scan_kernel<4, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+      else mfma_scan_kernel<2, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
 #else
       if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});

@@ -24,7 +24,8 @@ DATASETS = [
      synth.all_pairs(200, np.repeat(np.arange(100), 2))),
     ("40 img x 500, 780 pairs", synth.sfm_database(40, 500, 2026, share_frac=0.5, window=12), synth.all_pairs(40)),
 ]
-for title, (db, off), pairs in DATASETS:
+ONLY_FIRST = len(sys.argv) > 1 and sys.argv[1] == 'first'  # profiling: the default shape on euroc_V1's sizes
+for title, (db, off), pairs in (DATASETS[:1] if ONLY_FIRST else DATASETS):
     print(title)
     sizes = np.diff(off.astype(np.int64))
     m = vsm.Matcher(0)
@@ -35,7 +36,9 @@ for title, (db, off), pairs in DATASETS:
     out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     m.set_profiling(True)
     ref = None
-    for name, v in (("default", 0), ("rmax 4", 0x40000008), ("rmax 2", 0x20000008), ("rmax 1", 0x10000008), ("latency shape", 1)):
+    for name, v in ((("default", 0),) if ONLY_FIRST else (("default", 0), ("rmax 4", 0x40000008), ("rmax 2", 0x20000008), ("rmax 1", 0x10000008), ("latency shape", 1),
+                                                                          ("rmax 4, 1 job/wave", 0x40100008), ("rmax 4, 2 jobs/wave", 0x40200008),
+                                                                          ("rmax 4, 4 jobs/wave", 0x40400008), ("default again", 0))):
         m.set_variant(v)
         best = 1e9
         for _ in range(10):

@@ -116,13 +116,21 @@ constexpr int GROUP_D_256 = 0x41000000;   // bits of 8.0 = D' of distance 256
 // pipeline over (32 train rows, query block) steps: the four MFMAs of the next step are issued
 // before the minimum tree of the current one (two accumulator sets); sched_group_barriers
 // interleave them, three VALU instructions behind each MFMA.
-template <int NB>
-__device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
-                                                 const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
-                                                 u32 split_stride, uint2* __restrict__ scratch,
-                                                 const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
-  const u32 per = (job.nt + splits - 1) / splits;
-  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
+//
+// A RUN: the wave goes on with the jobs j0 + 1, j0 + 2, ... < j1 for as long as they have the SAME
+// query set as job j0 (consecutive pairs of an all-pairs list share their first image, sfm.cpp:1285-1290;
+// so do the candidate pairs of match_bow), keeping the expanded query operands in registers: the
+// wave launch, the load of the queries and their expansion (224 instructions at NB = 8) are paid once
+// per run instead of once per job.  Returns the first job it did not do.  RUNS = false compiles the
+// loop away (one job per call): the loop costs registers (NB 8: 237 -> 252, still two waves per
+// SIMD; NB 4: 166 -> 190 and NB 2: 117 -> 140 would each lose a wave per SIMD), so only the
+// 256-query-tile kernel of the batched scan has it.
+template <int NB, bool RUNS>
+__device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
+                                             const Job* __restrict__ jobs, u32 j0, u32 j1, u32 q0, u32 lane,
+                                             u32 split, u32 splits, u32 split_stride, uint2* __restrict__ scratch,
+                                             const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
+  Job job = jobs[j0];
   const u32 c = lane & 31, h = lane >> 5;
 
   u32 m88 = 0x88888888u, c22 = 0x22222222u;
@@ -139,6 +147,10 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
     B[b][3] = expand_bits_r(~w.w, m88, c22);
   }
   const int init = d_lim >= 256u ? GROUP_D_256 : GROUP_D_BASE | (int)(d_lim << 15);
+  u32 j = j0;
+  for (;;) {
+  const u32 per = (job.nt + splits - 1) / splits;
+  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
   int best[NB], second[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) best[b] = second[b] = init;
@@ -268,23 +280,31 @@ __device__ __forceinline__ void mfma_scan_tile(const u32x4* __restrict__ qbase, 
     if (h == 0 && qi < job.nq) out[colb] = make_uint2(kb, ks);
     store_accept_mask(acc, job, lane, q0e + b * 32, h == 0 && qi < job.nq, kb, ks);
   }
+  // the next job of the run, if it scans for the same queries
+  // (fetching the next job's first rows behind this job's last step, so that they are there when
+  // the epilogue is done, changed nothing measurable and took the last four registers)
+  if (!RUNS || ++j >= j1) break;
+  const Job nx = jobs[j];
+  if (nx.q_off != job.q_off || nx.nq != job.nq || nx.qlist_off != NO_QLIST || job.qlist_off != NO_QLIST) break;
+  job = nx;
+  }
+  return RUNS ? j : j0 + 1;
 }
 
 // The grid counts queries in units of 64, a tile in blocks of 32: when the last block of a job's last
 // tile holds no query at all (2000 queries: the eighth 256-query tile has 208, six and a half blocks)
 // the tile runs with one block less -- 1/64 of the MFMA work of a 2000-query job.
-template <int NB>
-__device__ __forceinline__ void mfma_scan_tile_fit(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
-                                                     const Job& job, u32 q0, u32 lane, u32 split, u32 splits,
-                                                     u32 split_stride, uint2* __restrict__ scratch,
-                                                     const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
+template <int NB, bool RUNS>
+__device__ __forceinline__ u32 mfma_scan_run_fit(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
+                                                 const Job* __restrict__ jobs, u32 j0, u32 j1, u32 nq, u32 q0, u32 lane,
+                                                 u32 split, u32 splits, u32 split_stride, uint2* __restrict__ scratch,
+                                                 const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
 #ifndef VSM_TILE_FIT
 #define VSM_TILE_FIT 1  // 0: A/B builds only
 #endif
-  if (VSM_TILE_FIT && NB > 1 && q0 + (NB - 1) * 32 >= job.nq)
-    mfma_scan_tile<(NB > 1 ? NB - 1 : 1)>(qbase, tbase, job, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
-  else
-    mfma_scan_tile<NB>(qbase, tbase, job, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
+  if (VSM_TILE_FIT && NB > 1 && q0 + (NB - 1) * 32 >= nq)
+    return mfma_scan_run<(NB > 1 ? NB - 1 : 1), RUNS>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
+  return mfma_scan_run<NB, RUNS>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
 }
 
 // WAVES == 1: one-wave workgroups, the grid of scan_kernel_adaptive<*, 1, *>: tiles of 32 * NBMAX
@@ -296,39 +316,54 @@ template <int NBMAX, int WAVES = 1>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
     u32 splits, u32 split_stride, uint2* __restrict__ scratch, const u32* __restrict__ qlist, u32 tiles_per_job,
-    u32 d_lim, AcceptMask acc) {
+    u32 d_lim, AcceptMask acc, u32 jobs_per_wave) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
-  u32 job_id, t;
+  // a wave's jobs [j0, j1) (WAVES == 1: jobs_per_wave consecutive ones, see mfma_scan_run) and the
+  // tile t it does of each
+  u32 j0, j1, t;
   if (WAVES == 1 && tiles_per_job) {
-    const u32 per_group = 8 * tiles_per_job;
-    const u32 group = blockIdx.x / per_group, r = blockIdx.x - group * per_group;
+    const u32 per_super = 8 * tiles_per_job;  // eight groups of jobs_per_wave jobs: one per XCD
+    const u32 super = blockIdx.x / per_super, r = blockIdx.x - super * per_super;
     t = r >> 3;
-    job_id = group * 8 + (r & 7);
-    if (job_id >= n_jobs) return;
+    j0 = (super * 8 + (r & 7)) * jobs_per_wave;
+    j1 = min(j0 + jobs_per_wave, n_jobs);
+  } else if (WAVES == 1) {
+    const u32 n_groups = (n_jobs + jobs_per_wave - 1) / jobs_per_wave;
+    t = blockIdx.x / n_groups;
+    j0 = (blockIdx.x - t * n_groups) * jobs_per_wave;
+    j1 = min(j0 + jobs_per_wave, n_jobs);
   } else {
     const u32 wg_of_job = blockIdx.x / n_jobs;
-    job_id = blockIdx.x - wg_of_job * n_jobs;
+    j0 = blockIdx.x - wg_of_job * n_jobs;
+    j1 = j0 + 1;
     t = wg_of_job * WAVES + wave;
   }
-  const Job job = jobs[job_id];
   constexpr u32 RMAX = NBMAX / 2;  // tiles are counted in units of 64 queries, as adaptive_tiles does
-  const u32 n64 = (job.nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
-  if (t < full) {
-    mfma_scan_tile_fit<NBMAX>(qbase, tbase, job, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
-    return;
-  }
-  u32 k = t - full, q0 = full * 64 * RMAX;
-  if (RMAX > 2 && (rem & 2)) {
-    if (k == 0) {
-      mfma_scan_tile_fit<4>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
-      return;
+  constexpr bool RUNS = WAVES == 1 && NBMAX == 8;  // else jobs_per_wave is 1 (the host sees to it)
+  // tile t of job j (and of the jobs after it that share its queries); returns the next job
+  auto tile_of = [&](u32 j) -> u32 {
+    const u32 nq = jobs[j].nq;
+    const u32 n64 = (nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
+    if (t < full) {
+      return mfma_scan_run_fit<NBMAX, RUNS>(qbase, tbase, jobs, j, j1, nq, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
     }
-    k--;
-    q0 += 128;
+    u32 k = t - full, q0 = full * 64 * RMAX;
+    if (RMAX > 2 && (rem & 2)) {
+      if (k == 0)
+        return mfma_scan_run_fit<4, RUNS>(qbase, tbase, jobs, j, j1, nq, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+      k--;
+      q0 += 128;
+    }
+    if ((rem & 1) && k == 0)
+      return mfma_scan_run_fit<2, RUNS>(qbase, tbase, jobs, j, j1, nq, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+    return j + 1;  // this job has no tile t
+  };
+  if (RUNS) {
+    for (u32 j = j0; j < j1;) j = tile_of(j);
+  } else if (j0 < j1) {
+    tile_of(j0);
   }
-  if ((rem & 1) && k == 0)
-    mfma_scan_tile_fit<2>(qbase, tbase, job, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
 }
 
 }  // namespace vsm

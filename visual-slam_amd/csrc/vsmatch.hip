@@ -280,6 +280,7 @@ struct ScanShape {
   bool uniform;   // every job has exactly `tiles` tiles (grouped block order, see the kernel)
   bool fkey;      // a split scans <= FKEY_MAX_SET rows: float keys (popcount) / 10-bit step tags (matrix cores)
   bool mfma;      // matrix-core scan (mfma_scan.h); else the popcount scan (experiment knob only)
+  u32 jobs_per_wave = 1;  // matrix-core adaptive scan: consecutive jobs a wave runs over (mfma_scan_run)
 };
 
 // Most tiles the adaptive kernels can need for a job of at most max_nq queries (the tile
@@ -298,6 +299,7 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
 //   bits 8-15   number of train splits
 //   bit 16      no pruning of the backward pass
 //   bit 17      popcount scan with integer keys (FILL 2) instead of float keys (FILL 8)
+//   bits 20-23  consecutive jobs per wave of the matrix-core batched scan (0 = the library's choice)
 //   bit 25      popcount scan everywhere (the formulation of BASELINE.json's north_star)
 //   bit 26      popcount scan in the pruned backward pass only
 //   bit 27      popcount scan for the latency shape only
@@ -332,7 +334,6 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
     // uniform 0.580 / 0.584 / 0.631, 96 x 2000 dense 2.52 / 2.57 / 2.72, 2048 pairs of 2000 x 2000
     // 0.739 / 0.763 / 0.831.  (Round 1's rule -- smaller tiles until a launch has 131072 waves --
     // was tuned on the popcount scan, whose waves cost the same per query at every tile size.)
-    (void)jobs_per_launch;
     if (uniform_tiles && avg_tiles && !uniform_tiles[1] && avg_tiles[1] < 4.0) s.rmax = 2;
     const int force = (variant >> 28) & 0x7;
     if (force == 1 || force == 2 || force == 4) s.rmax = force;
@@ -358,6 +359,15 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
   const u32 per = (max_nt + s.splits - 1) / s.splits;
   s.fkey = per <= FKEY_MAX_SET;
   s.mfma = s.fkey && !(variant & KNOB_POPCOUNT) && (s.adaptive || (s.R == 1 && !(variant & KNOB_POPCOUNT_LATENCY)));
+  // Runs of consecutive jobs per wave (mfma_scan.h, mfma_scan_run): as long as >= 32768 waves are
+  // left (16 rounds of the 2048 resident ones: the tail of a launch of four-job waves stays small)
+  s.jobs_per_wave = 1;
+  if (s.adaptive && s.mfma && s.splits == 1 && s.rmax == 4) {  // the 256-query-tile kernel only (mfma_scan.h)
+    const u64 w = (jobs_per_launch ? jobs_per_launch : n_jobs) * (u64)s.tiles;
+    while (s.jobs_per_wave < 4 && w / (2 * s.jobs_per_wave) >= 32768) s.jobs_per_wave *= 2;
+    const int fj = (variant >> 20) & 0xf;  // knob bits 20-23: forced
+    if (fj) s.jobs_per_wave = (u32)fj;
+  }
   return s;
 }
 
@@ -371,7 +381,8 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   u64 blocks = n_jobs * sh.wgs_per_job;
   dim3 block(256);
   if (sh.adaptive) {
-    blocks = (sh.uniform ? (n_jobs + 7) / 8 * 8 : n_jobs) * sh.tiles;
+    const u64 groups = sh.mfma ? (n_jobs + sh.jobs_per_wave - 1) / sh.jobs_per_wave : n_jobs;  // mfma_scan_run
+    blocks = (sh.uniform ? (groups + 7) / 8 * 8 : groups) * sh.tiles;
     block = dim3(64);
   }
   if (blocks > 0x7fffffffull) return fail(VSM_ERR_INVALID, "scan grid too large (%llu blocks)", (unsigned long long)blocks);
@@ -391,7 +402,7 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   const bool fill8 = sh.fkey && !(c->variant & KNOB_INT_KEYS);
 #define VSM_LAUNCH_M(NN, WW)                                                                                       \
   hipLaunchKernelGGL((mfma_scan_kernel<NN, WW>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
-                     split_stride, d_scratch, d_qlist, grouped, d_lim, acc)
+                     split_stride, d_scratch, d_qlist, grouped, d_lim, acc, sh.adaptive ? sh.jobs_per_wave : 1u)
 #define VSM_LAUNCH_A(FF, RR)                                                                                        \
   hipLaunchKernelGGL((scan_kernel_adaptive<FF, RR>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
                      split_stride, d_scratch, d_qlist, grouped)
