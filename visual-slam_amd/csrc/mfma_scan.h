@@ -311,7 +311,8 @@ __device__ __forceinline__ u32 mfma_scan_run_fit(const u32x4* __restrict__ qbase
 // queries and remainder tiles of half and a quarter of that, grouped or job-minor block order
 // (see there).  WAVES == 4: the grid of scan_kernel (4-wave workgroups, job-minor), used with
 // NBMAX == 2 for one stereo pair and for the pruned backward pass, most of whose workgroups find
-// nothing to do.  Registers: 237 (NBMAX 8: two waves per SIMD), 166 (4: three), 117 (2: four).
+// nothing to do.  Registers: 252 (NBMAX 8 with the job loop of mfma_scan_run, 237 without: two waves
+// per SIMD), 166 (4: three), 117 (2: four).
 template <int NBMAX, int WAVES = 1>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
