@@ -235,3 +235,36 @@ def test_match_bow_end_to_end():
     for p, (i, j) in enumerate(want):
         assert np.array_equal(matches[int(out_off[p]):int(out_off[p + 1])],
                               o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)), (i, j)
+
+
+def test_fuzz_small_databases_with_ties():
+    """150 seeded random cases: 0-40 images over a vocabulary of 1-30 words with values from a small
+    set (equal scores everywhere), empty images, queries that repeat words or name unknown ones,
+    0-50 results, a limit per query: scores bit-exact, order by (score, image index)."""
+    rng = np.random.default_rng(2026)
+    vals = np.array([0.125, 0.25, 0.5, 1.0, 1.0 / 3.0, 0.1])
+    with vsm.Matcher(0) as m:
+        for case in range(150):
+            n, vocab = int(rng.integers(0, 41)), int(rng.integers(1, 31))
+            db = []
+            for _ in range(n):
+                k = int(rng.integers(0, min(vocab, 10) + 1))
+                w = rng.choice(vocab, size=k, replace=False)
+                db.append(list(zip(w.tolist(), rng.choice(vals, size=k).tolist())))
+            queries = []
+            for _ in range(int(rng.integers(1, 6))):
+                k = int(rng.integers(0, 13))
+                w = rng.integers(0, vocab + 3, size=k)  # repeats and unknown words allowed in a query
+                queries.append(list(zip(w.tolist(), rng.choice(vals, size=k).tolist())))
+            k_res = int(rng.integers(0, 51))
+            limits = rng.integers(0, n + 3, size=len(queries)) if case % 2 else None
+            m.bowdb_upload(db)
+            res = m.bowdb_query(queries, k_res, db_limit=limits)
+            vecs = [(np.array([w for w, _ in v], np.uint32), np.array([x for _, x in v], np.float64)) for v in db]
+            for qi, (q, (idx, score)) in enumerate(zip(queries, res)):
+                lim = n if limits is None else min(int(limits[qi]), n)
+                qv = (np.array([w for w, _ in q], np.uint32), np.array([x for _, x in q], np.float64))
+                if k_res == 0:
+                    assert len(idx) == 0
+                    continue
+                check_query(oracle_db(vecs, lim), lim, qv, k_res, idx, score)
