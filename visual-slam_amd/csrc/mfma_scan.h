@@ -299,10 +299,7 @@ __device__ __forceinline__ u32 mfma_scan_run_fit(const u32x4* __restrict__ qbase
                                                  const Job* __restrict__ jobs, u32 j0, u32 j1, u32 nq, u32 q0, u32 lane,
                                                  u32 split, u32 splits, u32 split_stride, uint2* __restrict__ scratch,
                                                  const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
-#ifndef VSM_TILE_FIT
-#define VSM_TILE_FIT 1  // 0: A/B builds only
-#endif
-  if (VSM_TILE_FIT && NB > 1 && q0 + (NB - 1) * 32 >= nq)
+  if (NB > 1 && q0 + (NB - 1) * 32 >= nq)
     return mfma_scan_run<(NB > 1 ? NB - 1 : 1), RUNS>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
   return mfma_scan_run<NB, RUNS>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
 }

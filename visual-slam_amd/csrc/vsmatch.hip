@@ -500,11 +500,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   u32* d_counts = (u32*)c->counts.p;
   const u32x4* desc = (const u32x4*)d_desc;
   const u32 d_lim = accept_limit(prm);
-#ifdef VSM_AB_NO_GROUP_TABLE  // A/B builds only
-  const uint8_t* gmin = nullptr;
-#else
   const uint8_t* gmin = own_db ? (const uint8_t*)c->gmin.p : nullptr;  // the table belongs to the context's database
-#endif
 
   for (u64 first = 0; first < n_pairs; first += chunk) {
     const u32 n = (u32)std::min<u64>(chunk, n_pairs - first);
