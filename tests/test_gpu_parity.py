@@ -241,6 +241,33 @@ def test_real_like_database_batched():
                 assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], w), (hex(variant), k)
 
 
+@pytest.mark.parametrize("thr,ratio", [(70, 1.2), (1, 1.2), (40, 1.0), (40, 2.5), (100, 1.05), (100, 4.0), (200, 1.2),
+                                       (256, 1.0), (300, 0.5), (83, 1.2), (70, 0.0)])
+def test_batched_pruned_path_under_many_accept_tests(thr, ratio):
+    """The pruned batched path (accept masks by the scan's upper bound, nominate, pruned backward scan,
+    refinement after the cross-check with the group-table certificate) under thresholds and ratios
+    that move the accept limit, the certificate's bound min_second[d] + d and the table itself:
+    real-like database (crowded neighbourhoods, duplicates), 120 sampled pairs against the oracle,
+    with and without runs of jobs, and the unpruned path as a second opinion on every pair."""
+    with vsm.Matcher(0) as mm:
+        db, off = _real_like_database(64, 900, 5)
+        pairs = cases.synth.all_pairs(64)
+        mm.db_upload(db, off)
+        mm.set_variant(8)
+        offs, out = mm.match_pairs(pairs, thr, ratio)
+        mm.set_variant(RUN4 | TILE256 | 8)
+        offs_r, out_r = mm.match_pairs(pairs, thr, ratio)
+        mm.set_variant(NO_PRUNE | 8)
+        offs_n, out_n = mm.match_pairs(pairs, thr, ratio)
+    assert np.array_equal(offs, offs_r) and np.array_equal(out, out_r)
+    assert np.array_equal(offs, offs_n) and np.array_equal(out, out_n)
+    o = binding.port()
+    for k in np.random.default_rng(thr).choice(len(pairs), size=120, replace=False).tolist():
+        i, j = pairs[k]
+        want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], thr, ratio)
+        assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], want), (thr, ratio, k)
+
+
 def test_nn2_vs_oracle(m):
     for variant in (0, 8, 1, TILE64 | 8, TILE128 | 8, POPCOUNT | 8, POPCOUNT | INT_KEYS, POP_LAT | 1):
         m.set_variant(variant)
