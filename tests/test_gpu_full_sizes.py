@@ -151,3 +151,37 @@ def test_cereal_corners_file_in_matches_file_out(tmp_path):
         assert np.array_equal(md["matches"], want), (k, i, j)
     for f, (a, b) in enumerate(lr):  # match_stereo (sfm.cpp:1234-1244) on the same file
         assert np.array_equal(stereo[f], o.match(desc[off[a]:off[a + 1]], desc[off[b]:off[b + 1]], 70, 1.2)) and len(stereo[f]) > 50
+
+
+def test_attach_again_after_rewriting_the_buffer():
+    """vsm_db_attach reads the descriptors once (the group table of the consumer kernels): a caller
+    that rewrites an attached buffer attaches again (include/vsmatch.h).  Two real-like databases
+    through ONE device buffer, every list against the oracle both times."""
+    import torch
+    rng = np.random.default_rng(3)
+    real = np.concatenate([np.load(os.path.join(cases.GOLDEN, "ex3_kd0.npy")), np.load(os.path.join(cases.GOLDEN, "ex3_kd1.npy"))])
+    n_img, n_d = 48, 700
+    off = (np.arange(n_img + 1) * n_d).astype(np.uint32)
+    dbs = [np.ascontiguousarray(np.concatenate(
+        [real[rng.choice(len(real), n_d, replace=False)] ^ cases.synth.flip_masks(n_d, 40 + r, i, levels=(5,)) for i in range(n_img)]))
+        for r in range(2)]
+    pairs = cases.synth.all_pairs(n_img)
+    dev = torch.device("cuda", 0)
+    buf = torch.empty((n_img * n_d, 4), dtype=torch.int64, device=dev)
+    d_pairs = torch.from_numpy(pairs.view(np.int32).copy()).to(dev)
+    d_off = torch.empty(len(pairs) + 1, dtype=torch.int64, device=dev)
+    d_out = torch.empty((len(pairs) * n_d, 2), dtype=torch.int32, device=dev)
+    o = binding.port()
+    with vsm.Matcher(0) as m:
+        m.set_variant(8)  # the pruned batched path, whatever the job count says
+        for db in dbs:
+            buf.copy_(torch.from_numpy(db.view(np.int64)))
+            torch.cuda.synchronize()
+            m.db_attach(buf.data_ptr(), off)
+            total = m.match_pairs_device(d_pairs.data_ptr(), len(pairs), 70, 1.2, d_off.data_ptr(), d_out.data_ptr(), len(pairs) * n_d)
+            offs, lists = d_off.cpu().numpy(), d_out[:total].cpu().numpy()
+            assert total > 20000
+            for k in range(0, len(pairs), 9):
+                i, j = pairs[k]
+                want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+                assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want), (k, i, j)
