@@ -1,14 +1,15 @@
 #!/bin/bash
-# Runs the three C++ shim tests against a host-AddressSanitizer build of libvsmatch
+# Runs the C++ shim tests against a host-AddressSanitizer build of libvsmatch
 # (tools/asan_build/, built in the container with `hipcc -Xarch_host -fsanitize=address`;
 # device code is not instrumented).  Run on the GPU box through gpurun.
 # Build first (container):
 #   mkdir -p tools/asan_build && cd tools/asan_build
 #   hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -Xarch_host -fsanitize=address \
-#         -I../../include -I../../visual-slam_amd/csrc ../../visual-slam_amd/csrc/vsmatch.hip -o libvsmatch.so
-#   for t in shim_test shim_landmarks_test shim_orb_test; do /opt/rocm/lib/llvm/bin/clang++ -std=c++14 -O1 -g \
+#         -mllvm -amdgpu-mfma-vgpr-form -I../../include -I../../visual-slam_amd/csrc ../../visual-slam_amd/csrc/vsmatch.hip -o libvsmatch.so
+#   for t in shim_test shim_landmarks_test shim_orb_test shim_bowdb_test; do /opt/rocm/lib/llvm/bin/clang++ -std=c++14 -O1 -g \
 #         -fsanitize=address -I../../include ../../tests/cpp/$t.cpp -L. -lvsmatch -pthread -Wl,-rpath,'$ORIGIN' -o $t; done
-# Result of round 1 (gpurun_out/asan.log): all four runs clean; delete tools/asan_build afterwards (12 MB).
+# Results: round 1 all four runs clean; round 2 (with the BoW database shim and the multi-context batch) all six clean.
+# Delete tools/asan_build afterwards (16 MB).
 set -e
 cd "${GRAFT_REPO_ROOT:-.}"
 D=$(mktemp -d)
@@ -25,6 +26,16 @@ for k in ("kp_desc", "kp_xy", "proj_xy", "track_ids", "obs_off", "obs_desc", "ex
 xy, ang, desc = ex3_kd(0); img = ex3_image(0)
 np.ascontiguousarray(img).tofile(d + "/orb/img.bin"); np.array([img.shape[1], img.shape[0]], np.int32).tofile(d + "/orb/dims.bin")
 xy.tofile(d + "/orb/corners.bin"); ang.tofile(d + "/orb/angles.bin"); desc.tofile(d + "/orb/desc.bin")
+# BoW database shim: 120 images, the oracle's pair list for 7 candidates
+import importlib
+from oracle import binding
+synth = importlib.import_module("visual-slam_amd.synth")
+os.makedirs(d + "/bow")
+csr = synth.bow_vectors(120, 8000, 250, seed=31, window=5)
+want, _ = binding.match_bow_pairs([(i // 2, i % 2) for i in range(120)], *csr, 7)
+for a, name in zip(csr, ("off", "words", "values")):
+    a.tofile(f"{d}/bow/{name}.bin")
+want.astype(np.int32).tofile(d + "/bow/want.bin")
 PY
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
 G=tests/golden
@@ -32,4 +43,6 @@ timeout -k 10 120 tools/asan_build/shim_test $G/ex3_kd0.npy $G/ex3_kd1.npy $G/ex
 timeout -k 10 120 tools/asan_build/shim_landmarks_test $D/lm
 timeout -k 10 120 tools/asan_build/shim_orb_test $D/orb
 timeout -k 10 120 tools/asan_build/shim_orb_test $D/orb detect
+timeout -k 10 120 tools/asan_build/shim_bowdb_test $D/bow/off.bin $D/bow/words.bin $D/bow/values.bin $D/bow/want.bin 7 | tail -1
+VSM_DEVICES=0,0 timeout -k 10 120 tools/asan_build/shim_test $G/ex3_kd0.npy $G/ex3_kd1.npy $G/ex3_matches.npy | tail -1
 echo "asan: all shim tests clean"
