@@ -377,7 +377,7 @@ def main():
                        "= 19.66 T comparisons/s; the popcount (v_xor + v_bcnt) roofline the path was first built to is "
                        "2.84 T comparisons/s at measured issue rates, 2.46 T nominal",
         "kernel_gcomps": fwd["comparisons"] / (fwd["scan_ms"] * 1e-3) / 1e9,
-        "backward_pruned": {"kernel": "mfma_scan_kernel<2,4>", "launches": bwd["launches"],
+        "backward_pruned": {"kernel": "mfma_scan_kernel<4,4>", "launches": bwd["launches"],
                             "avg_launch_ms": bwd["scan_ms"] / max(1, bwd["launches"]),
                             "kernel_gcomps": (bwd["comparisons"] / (bwd["scan_ms"] * 1e-3) / 1e9) if bwd["scan_ms"] else None},
         "evaluated_over_reference_equivalent": scan_comps / comps_rank,

@@ -417,8 +417,9 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
     if (sh.rmax == 4) { if (fill8) VSM_LAUNCH_A(8, 4); else VSM_LAUNCH_A(2, 4); }
     else if (sh.rmax == 2) { if (fill8) VSM_LAUNCH_A(8, 2); else VSM_LAUNCH_A(2, 2); }
     else { if (fill8) VSM_LAUNCH_A(8, 1); else VSM_LAUNCH_A(2, 1); }
-  } else if (sh.mfma) {  // 64-query tiles in 4-wave workgroups: one stereo pair, the pruned backward pass
-    VSM_LAUNCH_M(2, 4);
+  } else if (sh.mfma) {  // 4-wave workgroups: one stereo pair, the pruned backward pass
+    if (sh.R == 2) VSM_LAUNCH_M(4, 4);  // the pruned backward pass: 128-query tiles
+    else VSM_LAUNCH_M(2, 4);           // one stereo pair: 64-query tiles
   } else if (sh.R == 4) {
     if (fill8) VSM_LAUNCH(4, 8); else VSM_LAUNCH(4, 2);
   } else {
@@ -485,16 +486,22 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     acc = AcceptMask{(const uint16_t*)c->lut.p, prm.threshold, (u32*)c->accmask.p};
   }
   // Backward jobs of the pruned pass scan ragged nominated lists whose lengths only the device
-  // knows: fixed 64-query tiles in 4-wave workgroups (matrix-core scan: 32 * 2 queries per wave).
-  // Adaptive tiles were measured here twice and do not pay: with the popcount scan a sparse
-  // batch went 0.45 -> 1.18 ms per launch and a dense one 4.4 -> 5.4 ms; with the matrix-core
-  // scan (256-query tiles) sparse 0.137 -> 0.153 ms, dense 1.59 -> 1.62 ms.  One looping workgroup
-  // per job instead of eight mostly idle ones: sparse 0.144 -> 0.172 ms, dense 1.50 -> 1.36 ms.
+  // knows: fixed tiles in 4-wave workgroups -- 128 queries per wave on the matrix cores (NB 4: real-like
+  // batch 1.98 -> 1.84 ms, dense 0.82 -> 0.75, sparse 0.20 -> 0.18 against 64-query tiles, which the
+  // popcount scan keeps; 256-query tiles: 2.18 / 0.74 / 0.25).
+  // Adaptive tiles in one-wave workgroups were measured here twice and do not pay: with the popcount
+  // scan a sparse batch went 0.45 -> 1.18 ms per launch and a dense one 4.4 -> 5.4 ms; with the
+  // matrix-core scan (256-query tiles) sparse 0.137 -> 0.153 ms, dense 1.59 -> 1.62 ms.  One looping
+  // workgroup per job instead of eight mostly idle ones: sparse 0.144 -> 0.172 ms, dense 1.50 -> 1.36 ms.
   ScanShape shb = sh;
   shb.adaptive = false;
   shb.R = 1;
   shb.wgs_per_job = std::max(1u, ((max_n + 63) / 64 + 3) / 4);
   shb.mfma = sh.fkey && !(c->variant & (KNOB_POPCOUNT | KNOB_POPCOUNT_BACKWARD));
+  if (shb.mfma) {  // matrix cores: 128-query tiles (NB 4, remainders of 64 and fewer), four per workgroup
+    shb.R = 2;
+    shb.wgs_per_job = std::max(1u, (adaptive_tiles_bound(max_n, 2) + 3) / 4);
+  }
   Job* d_jobs = (Job*)c->jobs.p;
   uint2* d_scratch = (uint2*)c->scratch.p;
   u32* d_counts = (u32*)c->counts.p;
