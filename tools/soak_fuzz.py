@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Randomised differential soak of the batched matcher against the oracle (GPU box, through gpurun).
+
+    python3 tools/soak_fuzz.py [seconds=240] [seed=1]
+
+Each case draws a database (uniform / ragged image sizes incl. empty images; planted overlap,
+real-ORB statistics or heavy duplicates), an accept test (threshold, ratio), a pair list (random
+ordered pairs, both orientations, repeats, self pairs) and an experiment-knob setting, runs
+vsm_match_pairs and compares EVERY pair's list with the oracle port (16 threads over pairs).
+Prints one line per case and a summary; exits 1 at the first difference, naming the case.
+Not a test (the -m gpu suite holds the fixed cases): a tool for hunting rare cases after a change
+to the scan, the pruned backward pass or the refinement.
+"""
+import importlib
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import binding  # noqa: E402
+
+synth = importlib.import_module("visual-slam_amd.synth")
+matcher = importlib.import_module("visual-slam_amd.matcher")
+
+TILE256, TILE128, TILE64 = 0x40000000, 0x20000000, 0x10000000
+POPCOUNT, POP_BACK, NO_PRUNE, INT_KEYS = 1 << 25, 1 << 26, 1 << 16, 1 << 17
+RUN = lambda j: j << 20  # noqa: E731
+VARIANTS = [0, 0, 0, 0, TILE256, TILE128, TILE64, NO_PRUNE, POP_BACK, POPCOUNT | TILE256, POPCOUNT | INT_KEYS | TILE64,
+            RUN(2) | TILE256, RUN(3) | TILE256, RUN(4), RUN(8) | TILE256, RUN(8) | NO_PRUNE | TILE256, 0x0208, 0x0308, 8, 4, 1]
+
+
+def real_pool():
+    g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    return np.concatenate([np.load(os.path.join(g, "ex3_kd0.npy")), np.load(os.path.join(g, "ex3_kd1.npy"))])
+
+
+def make_database(rng, real, case):
+    n_img = int(rng.integers(2, 41))
+    kind = rng.choice(["planted", "real", "dups"], p=[0.45, 0.4, 0.15])
+    if rng.random() < 0.4:
+        sizes = np.full(n_img, int(rng.choice([1, 31, 32, 33, 64, 200, 333, 500, 777, 1000, 1500, 2000])))
+    else:
+        hi = int(rng.choice([70, 300, 1100, 2600]))
+        sizes = rng.integers(0, hi + 1, size=n_img)
+        sizes[rng.random(n_img) < 0.08] = 0
+    sizes = np.minimum(sizes, max(1, 30000 // n_img)).astype(np.int64)
+    off = np.zeros(n_img + 1, np.uint32)
+    off[1:] = np.cumsum(sizes)
+    total = int(off[-1])
+    if kind == "planted" and sizes.min() > 0:
+        db, off = synth.sfm_database(n_img, [int(s) for s in sizes], seed=10_000 + case,
+                                     share_frac=float(rng.uniform(0.1, 0.9)), window=int(rng.integers(1, n_img + 1)))
+    elif kind == "dups":
+        base = synth.random_descriptors(max(1, total // 6 + 1), seed=20_000 + case)
+        db = base[rng.integers(0, len(base), size=total)] ^ synth.flip_masks(max(total, 1), 3, case, levels=(7, 8))[:total]
+        db[rng.random(total) < 0.5] = base[0]
+    else:
+        kind = "real" if kind != "planted" else "real(ragged)"
+        flips = synth.flip_masks(max(total, 1), 5, case, levels=(int(rng.integers(4, 7)),))[:total]
+        db = real[rng.integers(0, len(real), size=total)] ^ flips
+    return np.ascontiguousarray(db, dtype=np.uint64).reshape(-1, 4), off.astype(np.uint32), kind
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    real = real_pool()
+    m = matcher.Matcher(0)
+    o = binding.port()
+    pool = ThreadPoolExecutor(16)
+    t_end = time.time() + budget
+    case = n_pairs_total = n_matches_total = 0
+    while time.time() < t_end:
+        case += 1
+        db, off, kind = make_database(rng, real, seed * 100_000 + case)
+        n_img = len(off) - 1
+        if len(db) == 0:
+            continue
+        n_pairs = int(rng.integers(1, 400))
+        pairs = rng.integers(0, n_img, size=(n_pairs, 2)).astype(np.uint32)
+        if rng.random() < 0.5:
+            pairs = np.concatenate([pairs, pairs[: n_pairs // 2, ::-1]])
+        if rng.random() < 0.3:  # the all-pairs order of sfm.cpp:1285-1290: runs of jobs with one query image
+            pairs = synth.all_pairs(n_img)[: 2000]
+        thr, ratio = (70, 1.2) if rng.random() < 0.5 else (int(rng.integers(1, 301)), float(rng.uniform(0.5, 3.0)))
+        variant = int(rng.choice(VARIANTS))
+        m.db_upload(db, off)
+        m.set_variant(variant)
+        try:
+            offs, lists = m.match_pairs(pairs, thr, ratio)
+        finally:
+            m.set_variant(0)
+        assert int(offs[0]) == 0 and int(offs[-1]) == len(lists)
+
+        def check(k):
+            i, j = int(pairs[k, 0]), int(pairs[k, 1])
+            out = np.empty((max(1, min(int(off[i + 1] - off[i]), int(off[j + 1] - off[j]))), 2), np.int32)
+            n = o.match_db_pair(db, off, i, j, thr, ratio, out)
+            return np.array_equal(lists[int(offs[k]):int(offs[k + 1])], out[:n])
+
+        ok = list(pool.map(check, range(len(pairs))))
+        n_pairs_total += len(pairs)
+        n_matches_total += len(lists)
+        line = (f"case {case} seed {seed}: {kind} {n_img} images, {len(db)} descriptors, {len(pairs)} pairs, thr {thr} "
+                f"ratio {ratio:.4f}, variant {variant:#x}: {len(lists)} matches")
+        if not all(ok):
+            bad = [k for k, v in enumerate(ok) if not v]
+            print(line + f" -- DIFFERENT at pairs {bad[:10]} ({[pairs[k].tolist() for k in bad[:10]]})", flush=True)
+            return 1
+        if case % 20 == 0:
+            print(line, flush=True)
+    print(f"soak: {case} cases, {n_pairs_total} pairs, {n_matches_total} matches, all equal to the oracle", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
