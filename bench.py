@@ -582,6 +582,35 @@ def main():
                 "stereo_matches": kf[2], "landmark_matches_synthetic_map": kf[3],
                 "note": "4 library calls per keyframe: 2 x (detect + angles + descriptors), stereo match, landmark match "
                         "(2500 synthetic projected landmarks); images from tests/golden/euroc_subset"}
+            # the front end over a whole image set in one call (the loop of detect_keypoints(), sfm.cpp:1191-1201):
+            # 164 images (the size of data/euroc_V1) made of the 8 real frames that travel, shifted
+            allf = [np.array(Image.open(os.path.join(sub, f))) for f in sorted(f for f in os.listdir(sub) if f.endswith(".jpg"))]
+            imgs = [np.ascontiguousarray(np.roll(allf[k % len(allf)], (3 * (k // len(allf)), 5 * (k // len(allf))), (0, 1)))
+                    for k in range(164)]
+            for _ in range(2):
+                boff, bxy, bang, bdesc = m.detect_and_describe_batch(imgs, 1500, True)
+            t = time.perf_counter()
+            for _ in range(5):
+                boff, bxy, bang, bdesc = m.detect_and_describe_batch(imgs, 1500, True)
+            bt = (time.perf_counter() - t) / 5
+            t = time.perf_counter()
+            one = [m.detect_and_describe(im, 1500, True) for im in imgs]
+            lt = time.perf_counter() - t
+            same = all(np.array_equal(bxy[boff[k]:boff[k + 1]], one[k][0]) and np.array_equal(bang[boff[k]:boff[k + 1]], one[k][1])
+                       and np.array_equal(bdesc[boff[k]:boff[k + 1]], one[k][2]) for k in range(len(imgs)))
+            t = time.perf_counter()
+            m.detect_and_describe_batch(imgs, 1500, True, keep_as_database=True, want=())
+            bp = synth.all_pairs(len(imgs), frame_of=np.arange(len(imgs)) // 2)
+            bo, bl = m.match_pairs(bp, a.threshold, a.ratio)
+            e2e = time.perf_counter() - t
+            extra["detect_and_describe_batch_164img_752x480"] = {
+                "ms_per_call": bt * 1e3, "images_per_s": len(imgs) / bt, "keypoints": int(boff[-1]),
+                "image_by_image_ms": lt * 1e3, "equal_to_image_by_image": bool(same),
+                "images_to_match_lists_ms": e2e * 1e3, "pairs_matched": int(len(bp)), "matches": int(len(bl)),
+                "note": "vsm_detect_and_describe_batch: host images in, host corners / angles / descriptors out; "
+                        "images_to_match_lists_ms = the same with the descriptors kept on the device as the database "
+                        "(keep_as_database) + vsm_match_pairs over all non-stereo pairs (sfm.cpp:1285-1290): images in, "
+                        "match lists out"}
         except (OSError, ImportError):
             pass
         # next row N4 (parity unpinned): vocabulary-tree descent (bow_voc.h:57-92) of one image's 1500

@@ -13,6 +13,7 @@
 //                              KeypointsData& kd, bool rotate_features);
 //   void visnav::computeDescriptors(const pangolin::ManagedImage<uint8_t>& img_raw,
 //                                   KeypointsData& kd);
+// and, for the loop over all images at src/sfm.cpp:1191-1201, detectKeypointsAndDescriptorsBatch.
 //
 // Same argument order and meaning; kd.corner_angles / kd.corner_descriptors are resized to
 // kd.corners.size() and filled.  Image and keypoint types are template parameters deduced at
@@ -119,6 +120,56 @@ inline void detectKeypointsAndDescriptors(const ImageT& img_raw, KeypointsDataT&
   kd.corner_descriptors.resize(count);
   using Corner = typename std::decay<decltype(kd.corners[0])>::type;
   for (size_t i = 0; i < count; i++) kd.corners.push_back(Corner{xy[2 * i], xy[2 * i + 1]});
+}
+
+// The loop of detect_keypoints(), src/sfm.cpp:1191-1201, in one call: kds[i] receives what
+// detectKeypointsAndDescriptors(*images[i], kds[i], num_features, rotate_features) gives, for every
+// image of the set (one size and pitch) -- each device stage runs once for the whole set.
+// keep_as_database: the descriptors also stay on this thread's context as its database, image i =
+// database image i, ready for matchDescriptorsBatch-style calls on the same context without an upload.
+template <class ImageT, class KeypointsDataT>
+inline void detectKeypointsAndDescriptorsBatch(const std::vector<const ImageT*>& images, std::vector<KeypointsDataT>& kds,
+                                               int num_features, bool rotate_features, bool keep_as_database = false) {
+  const size_t n_img = images.size();
+  kds.resize(n_img);
+  for (auto& kd : kds) {
+    kd.corners.clear();
+    kd.corner_angles.clear();
+    kd.corner_descriptors.clear();
+  }
+  if (n_img == 0) return;
+  std::vector<const uint8_t*> ptrs(n_img);
+  for (size_t i = 0; i < n_img; i++) {
+    if (images[i]->w != images[0]->w || images[i]->h != images[0]->h || images[i]->pitch != images[0]->pitch)
+      throw std::runtime_error("visnav::detectKeypointsAndDescriptorsBatch (GPU): the images differ in size or pitch");
+    ptrs[i] = images[i]->ptr;
+  }
+  const int w = int(images[0]->w), h = int(images[0]->h);
+  std::vector<uint32_t> off(n_img + 1, 0);
+  size_t cap = n_img * (num_features > 0 ? size_t(num_features) : size_t(4096));
+  std::vector<double> xy, ang;
+  std::vector<std::bitset<256>> desc;
+  for (int attempt = 0;; attempt++) {
+    xy.resize(2 * cap + 2);
+    ang.resize(cap + 1);
+    desc.resize(cap + 1);
+    const int rc = vsm_detect_and_describe_batch(vsm_detail::thread_context(), ptrs.data(), n_img, w, h, size_t(images[0]->pitch),
+                                                 num_features, rotate_features ? 1 : 0, off.data(), xy.data(), ang.data(),
+                                                 reinterpret_cast<uint64_t*>(desc.data()), cap, keep_as_database ? 1 : 0);
+    if (rc == VSM_ERR_CAPACITY && attempt == 0 && off[n_img] > cap) {  // num_features == 0: now the need is known
+      cap = off[n_img];
+      continue;
+    }
+    vsm_detail::orb_check(rc, "detectKeypointsAndDescriptorsBatch");
+    break;
+  }
+  using Corner = typename std::decay<decltype(kds[0].corners[0])>::type;
+  for (size_t i = 0; i < n_img; i++) {
+    kds[i].corners.reserve(off[i + 1] - off[i]);
+    for (size_t k = off[i]; k < off[i + 1]; k++) kds[i].corners.push_back(Corner{xy[2 * k], xy[2 * k + 1]});
+    kds[i].corner_angles.assign(ang.begin() + off[i], ang.begin() + off[i + 1]);
+    kds[i].corner_descriptors.assign(desc.begin() + off[i], desc.begin() + off[i + 1]);
+  }
 }
 
 // keypoints.h:243-244 in one call (one image upload).

@@ -243,6 +243,25 @@ int vsm_good_features_to_track(vsm_ctx* ctx, const uint8_t* img, int width, int 
 int vsm_detect_and_describe(vsm_ctx* ctx, const uint8_t* img, int width, int height, size_t pitch,
                             int num_features, int rotate_features, double* corners_out,
                             double* angles_out, uint64_t* desc_out, size_t cap, size_t* out_count);
+/*
+ * Replaces the loop of detect_keypoints(), src/sfm.cpp:1191-1201 (detectKeypointsAndDescriptors
+ * for every image of the dataset, one after the other): all n_img images in one call.  imgs[i]:
+ * HOST pointers to 8-bit images of one size (width, height, pitch).  Every device stage runs once
+ * per chunk of images (thousands at EuRoC size) with the image as a grid dimension; the host
+ * steps in between (the sequential minimum-distance pass of goodFeaturesToTrack; atan2 / cos / sin
+ * with the caller's libm) run on up to VSM_HOST_THREADS (default 8) threads.  Results are those of
+ * vsm_detect_and_describe image by image, bit for bit: out_offsets[n_img + 1] (always written),
+ * image i's keypoints at [out_offsets[i], out_offsets[i+1]) of corners_out[cap][2], angles_out[cap],
+ * desc_out[cap][4] (each may be NULL: not wanted).  VSM_ERR_CAPACITY if cap is too small for the
+ * wanted arrays (out_offsets then still holds the counts; n_img * num_features always suffices).
+ * keep_as_database != 0 (needs num_features > 0): the descriptors also stay on the device as the
+ * context's database, laid out by out_offsets as after vsm_db_upload, ready for vsm_match_pairs --
+ * images in, match lists out, descriptors never leave the GPU.
+ */
+int vsm_detect_and_describe_batch(vsm_ctx* ctx, const uint8_t* const* imgs, size_t n_img, int width,
+                                  int height, size_t pitch, int num_features, int rotate_features,
+                                  uint32_t* out_offsets, double* corners_out, double* angles_out,
+                                  uint64_t* desc_out, size_t cap, int keep_as_database);
 
 /*
  * Vocabulary tree of visnav::BowVocabulary (include/visnav/bow_voc.h:163-247), flattened:

@@ -56,7 +56,24 @@ int main(int argc, char** argv) {
     }
     for (size_t i = 0; i < want_ang.size(); i++)
       if (!(std::fabs(kdd.corner_angles[i] - want_ang[i]) < 1e-8)) return 1;
-    std::printf("detect shim ok: %zu corners, descriptors and angles equal the reference's golden file\n",
+    // the loop of sfm.cpp:1191-1201 in one call: the image, a flipped copy, the image again
+    std::vector<uint8_t> flipped(pix.rbegin(), pix.rend());
+    Image img2{size_t(dims[0]), flipped.data(), size_t(dims[0]), size_t(dims[1])};
+    KeypointsData kf;
+    visnav::detectKeypointsAndDescriptors(img2, kf, 1500, true);
+    std::vector<const Image*> set{&img, &img2, &img};
+    std::vector<KeypointsData> kds;
+    visnav::detectKeypointsAndDescriptorsBatch(set, kds, 1500, true);
+    const KeypointsData* want[3] = {&kdd, &kf, &kdd};
+    for (int i = 0; i < 3; i++)
+      if (kds[i].corners != want[i]->corners || kds[i].corner_angles != want[i]->corner_angles ||
+          kds[i].corner_descriptors != want[i]->corner_descriptors) {
+        std::fprintf(stderr, "FAIL: batch, image %d\n", i);
+        return 1;
+      }
+    visnav::detectKeypointsAndDescriptorsBatch(set, kds, 0, false, false);  // no limit: the capacity is found on the way
+    if (kds[0].corners.size() < kdd.corners.size() || kds[2].corners != kds[0].corners) return 1;
+    std::printf("detect shim ok: %zu corners, descriptors and angles equal the reference's golden file; batch of 3 equal\n",
                 kdd.corners.size());
     return 0;
   }

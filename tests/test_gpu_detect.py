@@ -111,3 +111,75 @@ def test_repeated_detection_is_bit_identical(m):
     for _ in range(20):
         got = m.detect_and_describe(img, 1500, True)
         assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+
+
+def _batch_images():
+    rng = np.random.default_rng(17)
+    imgs = [synth_image(752, 480, 40 + k) for k in range(5)]
+    imgs.append(rng.integers(0, 256, (480, 752)).astype(np.uint8))     # noise: > 4096 candidates wanted by the pass
+    imgs.append(np.full((480, 752), 90, np.uint8))                      # flat: no corner at all
+    imgs.append(ex3_image(0) if ex3_image(0).shape == (480, 752) else synth_image(752, 480, 3))
+    return imgs
+
+
+@pytest.mark.parametrize("num_features,rotate", [(1500, True), (200, False), (0, True)])
+def test_batch_front_end_equals_image_by_image(m, num_features, rotate):
+    """vsm_detect_and_describe_batch (the loop of detect_keypoints(), sfm.cpp:1191-1201, in one
+    call) against vsm_detect_and_describe image by image: offsets, corners, angles and descriptors
+    bit for bit; one image against the oracle as well."""
+    imgs = _batch_images()
+    off, xy, ang, desc = m.detect_and_describe_batch(imgs, num_features, rotate)
+    assert off[0] == 0 and off[-1] == len(xy) == len(ang) == len(desc)
+    for k, im in enumerate(imgs):
+        wxy, wang, wdesc = m.detect_and_describe(im, num_features, rotate)
+        s = slice(int(off[k]), int(off[k + 1]))
+        assert np.array_equal(xy[s], wxy) and np.array_equal(ang[s], wang) and np.array_equal(desc[s], wdesc), k
+    assert off[7] - off[6] == 0 and off[1] - off[0] > 100
+    o = binding.port()
+    oxy = o.detect_keypoints(imgs[2], num_features)
+    oa, od = o.orb_describe(imgs[2], oxy, rotate)
+    s = slice(int(off[2]), int(off[3]))
+    assert np.array_equal(xy[s], oxy) and np.array_equal(ang[s], oa) and np.array_equal(desc[s], od)
+
+
+def test_batch_front_end_into_the_database(m):
+    """Images in, match lists out: the batch front end leaves the descriptors on the device as the
+    context's database (keep_as_database), vsm_match_pairs follows with no upload -- equal to the
+    oracle's matchDescriptors on the descriptors the batch also returned; strided rows; a second
+    call replaces the database; only the wanted arrays are written."""
+    imgs = [synth_image(400, 300, 60 + k)[:, 5:395] for k in range(6)]   # pitch 400, width 390
+    off, xy, ang, desc = m.detect_and_describe_batch(imgs, 600, True, keep_as_database=True)
+    assert off[-1] > 600
+    pairs = cases.synth.all_pairs(len(imgs))
+    offs, lists = m.match_pairs(pairs, 90, 1.1)
+    o = binding.port()
+    for k, (i, j) in enumerate(pairs.tolist()):
+        want = o.match(desc[off[i]:off[i + 1]], desc[off[j]:off[j + 1]], 90, 1.1)
+        assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want), (i, j)
+    off2, xy2, ang2, desc2 = m.detect_and_describe_batch(imgs[:2], 300, False, keep_as_database=True, want=("descriptors",))
+    assert xy2 is None and ang2 is None and len(desc2) == off2[-1]
+    offs, lists = m.match_pairs(np.array([[0, 1]], np.uint32), 90, 1.1)
+    assert np.array_equal(lists, o.match(desc2[:off2[1]], desc2[off2[1]:], 90, 1.1))
+
+
+def test_batch_front_end_errors_and_capacity(m):
+    import ctypes as C
+    L = vsm.matcher.lib()
+    imgs = [synth_image(96, 64, 1), synth_image(96, 64, 2)]
+    ptrs = (C.c_void_p * 2)(*[im.ctypes.data for im in imgs])
+    off = np.zeros(3, np.uint32)
+    xy = np.zeros((4, 2))
+    rc = L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 50, 1, C.c_void_p(off.ctypes.data), C.c_void_p(xy.ctypes.data),
+                                         None, None, 4, 0)
+    want = [len(binding.port().detect_keypoints(im, 50)) for im in imgs]
+    assert rc == vsm.matcher.VSM_ERR_CAPACITY and list(np.diff(off)) == want and sum(want) > 4
+    assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 0, 1, C.c_void_p(off.ctypes.data), None, None, None, 0,
+                                           1) == vsm.matcher.VSM_ERR_INVALID      # a kept database needs num_features > 0
+    assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 95, 50, 1, C.c_void_p(off.ctypes.data), None, None, None, 0,
+                                           0) == vsm.matcher.VSM_ERR_INVALID      # pitch < width
+    assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 50, 1, None, None, None, None, 0, 0) == vsm.matcher.VSM_ERR_INVALID
+    # counts only (no array wanted), and the empty batch
+    assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 50, 1, C.c_void_p(off.ctypes.data), None, None, None, 0, 0) == 0
+    assert list(np.diff(off)) == want
+    off0, xy0, ang0, desc0 = m.detect_and_describe_batch([], 100)
+    assert list(off0) == [0] and len(xy0) == 0

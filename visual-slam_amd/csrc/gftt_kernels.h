@@ -8,6 +8,10 @@
 // kernels; the ordering of the candidates and the sequential minimum-distance pass stay on
 // the host (vsmatch.hip), as does the EDGE_THRESHOLD filter.
 //
+// Batches (vsm_detect_and_describe_batch): blockIdx.z is the image of a batch of equally sized
+// images; image z lives at img + z * img_stride and its work areas at z * (w * h) elements (the
+// candidate capacity `cap` is w * h), its (max key, count) pair at misc + 2 z.  One image: z = 0.
+//
 // Float arithmetic is kept exactly as the restatement in the checker does it: products and
 // sums in float with contraction off, the 3x3 box sums in double, correctly rounded sqrt.
 #pragma once
@@ -32,10 +36,12 @@ __device__ __forceinline__ float key_float(u32 k) {
 // grad[y * w + x] = (Dx, Dy): Sobel 3x3 scaled by 1 / (4 * 3 * 255) as cornerMinEigenVal
 // scales it for 8-bit input, block size 3, aperture 3.
 __global__ __launch_bounds__(256) void gftt_sobel_kernel(const uint8_t* __restrict__ img, int w, int h, u32 pitch,
-                                                         float2* __restrict__ grad) {
+                                                         float2* __restrict__ grad, size_t img_stride) {
 #pragma clang fp contract(off)
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
+  img += blockIdx.z * img_stride;
+  grad += blockIdx.z * ((size_t)w * h);
   const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = 2.0f * f1;
   const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
   const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * pitch;
@@ -60,6 +66,9 @@ __global__ __launch_bounds__(256) void gftt_mineig_kernel(const float2* __restri
 #pragma clang fp contract(off)
   __shared__ u32 wave_max[4];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  grad += blockIdx.z * ((size_t)w * h);
+  eig += blockIdx.z * ((size_t)w * h);
+  max_key += 2 * blockIdx.z;
   u32 key = 0;
   if (x < w && y < h) {
     double cxx[3], cxy[3], cyy[3];
@@ -106,21 +115,37 @@ __global__ __launch_bounds__(256) void gftt_candidates_kernel(const float* __res
                                                               u64* __restrict__ cand, u32* __restrict__ count,
                                                               u32 cap) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x < 1 || y < 1 || x >= w - 1 || y >= h - 1) return;
-  const float thr = (float)((double)key_float(*max_key) * quality);
-  const float v = eig[(size_t)y * w + x];
-  if (!(v > thr) || v == 0.0f) return;
-  bool is_max = true;
+  eig += blockIdx.z * ((size_t)w * h);
+  max_key += 2 * blockIdx.z;
+  count += 2 * blockIdx.z;
+  cand += blockIdx.z * (size_t)cap;
+  bool is_cand = x >= 1 && y >= 1 && x < w - 1 && y < h - 1;
+  float v = 0.0f;
+  if (is_cand) {
+    const float thr = (float)((double)key_float(*max_key) * quality);
+    v = eig[(size_t)y * w + x];
+    is_cand = v > thr && v != 0.0f;
+    if (is_cand) {
 #pragma unroll
-  for (int j = -1; j <= 1; j++)
+      for (int j = -1; j <= 1; j++)
 #pragma unroll
-    for (int i = -1; i <= 1; i++) {
-      float u = eig[(size_t)(y + j) * w + (x + i)];
-      if (!(u > thr)) u = 0.0f;
-      is_max = is_max && !(u > v);
+        for (int i = -1; i <= 1; i++) {
+          float u = eig[(size_t)(y + j) * w + (x + i)];
+          if (!(u > thr)) u = 0.0f;
+          is_cand = is_cand && !(u > v);
+        }
     }
-  if (!is_max) return;
-  const u32 slot = atomicAdd(count, 1u);
+  }
+  // one atomic per wave (the order of the list is arbitrary anyway; the sort that follows fixes it):
+  // a counter per image takes every candidate of that image, 15 k same-address atomics otherwise
+  const u64 m = __ballot(is_cand);
+  if (m == 0) return;
+  const u32 lane = threadIdx.x & 63;
+  u32 base = 0;
+  if (lane == (u32)__builtin_ctzll(m)) base = atomicAdd(count, (u32)__builtin_popcountll(m));
+  base = (u32)__shfl((int)base, __builtin_ctzll(m));
+  if (!is_cand) return;
+  const u32 slot = base + (u32)__builtin_popcountll(m & (((u64)1 << lane) - 1));
   if (slot < cap) cand[slot] = ((u64)float_key(v) << 32) | (u32)(y * w + x);
 }
 
@@ -131,12 +156,27 @@ __global__ __launch_bounds__(256) void gftt_candidates_kernel(const float* __res
 // host sort; the host falls back to std::sort above GFTT_RANK_SORT_MAX.
 constexpr u32 GFTT_RANK_SORT_MAX = 65536;
 constexpr u32 GFTT_RANK_BLOCK = 64;  // one wave per workgroup: 15 k candidates still cover ~all 256 CUs
+// (the bitonic sort of a batch, below: block size, padded size, and which images it orders)
+constexpr u32 GFTT_LDS_SORT_BLOCK = 16384;
+__host__ __device__ __forceinline__ u32 gftt_sort_size(u32 n) {
+  u32 N = 64;
+  while (N < n) N <<= 1;
+  return N;
+}
+__host__ __device__ __forceinline__ bool gftt_lds_sorts(u32 n, u32 cap) {
+  return n <= GFTT_RANK_SORT_MAX && gftt_sort_size(n) <= cap;
+}
+// skip_lds_sorted: images gftt_lds_sort_kernel orders (a batch) are left alone.
 __global__ __launch_bounds__(GFTT_RANK_BLOCK) void gftt_rank_sort_kernel(const u64* __restrict__ cand,
                                                                          const u32* __restrict__ count, u32 cap,
-                                                                         u64* __restrict__ sorted) {
+                                                                         u64* __restrict__ sorted, u32 skip_lds_sorted) {
   __shared__ u64 tile[256];
+  count += 2 * blockIdx.z;
+  cand += blockIdx.z * (size_t)cap;
+  sorted += blockIdx.z * (size_t)cap;
   const u32 n = min(*count, cap);
   if (n > GFTT_RANK_SORT_MAX || blockIdx.x * GFTT_RANK_BLOCK >= n) return;  // block-uniform
+  if (skip_lds_sorted && gftt_lds_sorts(n, cap)) return;
   const u32 i = blockIdx.x * GFTT_RANK_BLOCK + threadIdx.x;
   const u64 mine = i < n ? cand[i] : 0;
   u32 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -157,6 +197,76 @@ __global__ __launch_bounds__(GFTT_RANK_BLOCK) void gftt_rank_sort_kernel(const u
     }
   }
   if (i < n) sorted[(r0 + r1) + (r2 + r3)] = mine;
+}
+
+// A batch of images: the brute-force order above is n^2 work per image whatever the batch (15 k
+// candidates: 70 us of the whole chip), so a batch sorts each image's candidates with ONE workgroup
+// instead -- a bitonic network over the keys padded with zeros to a power of two N, descending -- and
+// the images run side by side on the CUs.  Blocks of GFTT_LDS_SORT_BLOCK keys (128 KB) are sorted in
+// LDS; for N beyond one block the merges with a partner distance >= the block run through global
+// memory (`sorted`, N <= cap entries), the rest of each merge again block by block in LDS.  Images
+// with more than GFTT_RANK_SORT_MAX candidates are left to the host, images whose N exceeds cap to
+// gftt_rank_sort_kernel (gftt_lds_sorts() says which).  blockIdx.x = image.
+// the merges of partner distance < span over the LDS block whose first key has global index g0
+__device__ __forceinline__ void gftt_lds_merge(u64* keys, u32 B, u32 g0, u32 k_first, u32 k_last, u32 j_first) {
+  for (u32 k = k_first; k <= k_last; k <<= 1)
+    for (u32 j = min(k >> 1, j_first); j > 0; j >>= 1) {
+      for (u32 t = threadIdx.x; t < B / 2; t += 1024) {
+        const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;  // the pair (i, i + j), bit j of i clear
+        const bool descending = ((g0 + i) & k) == 0;                    // the last merge (k = N) is descending throughout
+        const u64 a = keys[i], b = keys[l];
+        if ((a < b) == descending) {
+          keys[i] = b;
+          keys[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void gftt_lds_sort_kernel(const u64* __restrict__ cand, const u32* __restrict__ count,
+                                                             u32 cap, u64* sorted) {
+  extern __shared__ u64 gftt_sort_keys[];
+  u64* keys = gftt_sort_keys;
+  count += 2 * blockIdx.x;
+  cand += blockIdx.x * (size_t)cap;
+  sorted += blockIdx.x * (size_t)cap;
+  const u32 n = min(*count, cap);
+  if (n == 0 || !gftt_lds_sorts(n, cap)) return;  // block-uniform
+  const u32 N = gftt_sort_size(n), B = min(N, GFTT_LDS_SORT_BLOCK);
+  // every block sorted on its own, directions alternating as the network wants them
+  for (u32 g0 = 0; g0 < N; g0 += B) {
+    for (u32 i = threadIdx.x; i < B; i += 1024) keys[i] = g0 + i < n ? cand[g0 + i] : 0;  // 0 is below every real key
+    __syncthreads();
+    gftt_lds_merge(keys, B, g0, 2, B, B);
+    if (N == B) {
+      for (u32 i = threadIdx.x; i < n; i += 1024) sorted[i] = keys[i];
+      return;
+    }
+    for (u32 i = threadIdx.x; i < B; i += 1024) sorted[g0 + i] = keys[i];
+    __syncthreads();
+  }
+  // the merges across blocks
+  for (u32 k = 2 * B; k <= N; k <<= 1) {
+    for (u32 j = k >> 1; j >= B; j >>= 1) {
+      for (u32 t = threadIdx.x; t < N / 2; t += 1024) {
+        const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+        const bool descending = (i & k) == 0;
+        const u64 a = sorted[i], b = sorted[l];
+        if ((a < b) == descending) {
+          sorted[i] = b;
+          sorted[l] = a;
+        }
+      }
+      __syncthreads();  // global writes of this workgroup are visible to it after the barrier
+    }
+    for (u32 g0 = 0; g0 < N; g0 += B) {
+      for (u32 i = threadIdx.x; i < B; i += 1024) keys[i] = sorted[g0 + i];
+      __syncthreads();
+      gftt_lds_merge(keys, B, g0, k, k, B >> 1);
+      for (u32 i = threadIdx.x; i < B; i += 1024) sorted[g0 + i] = keys[i];
+      __syncthreads();
+    }
+  }
 }
 
 }  // namespace vsm

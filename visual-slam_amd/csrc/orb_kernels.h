@@ -19,13 +19,16 @@ namespace vsm {
 // m10 = sum dx * I(cx + dx, cy + dy), m01 = sum dy * I(.) over the disc dx^2 + dy^2 <= 225
 // clipped to the image (keypoints.h:166-193).  One wave per keypoint, 4 keypoints per
 // workgroup; lanes walk the 31 x 31 window row by row (x fastest: coalesced reads).
+// Batches: kp_img[k] (may be null: one image) names the image of keypoint k, at img + kp_img[k] * img_stride.
 __global__ __launch_bounds__(256) void orb_moments_kernel(const uint8_t* __restrict__ img, int w, int h,
                                                           u32 pitch, const double2* __restrict__ corners,
-                                                          u32 n, int2* __restrict__ moments) {
+                                                          u32 n, int2* __restrict__ moments,
+                                                          const u32* __restrict__ kp_img, size_t img_stride) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   const u32 k = blockIdx.x * 4 + wave;
   if (k >= n) return;
+  if (kp_img) img += kp_img[k] * img_stride;
   const double2 p = corners[k];
   const int cx = (int)p.x, cy = (int)p.y;  // keypoints.h:158-159 (truncation)
   int m10 = 0, m01 = 0;
@@ -58,11 +61,13 @@ __device__ __forceinline__ double round_half_away(double x) {  // C round(), key
 __global__ __launch_bounds__(256) void orb_descriptor_kernel(const uint8_t* __restrict__ img, int w, int h,
                                                              u32 pitch, const double2* __restrict__ corners,
                                                              const double2* __restrict__ cs, u32 n,
-                                                             u64* __restrict__ desc) {
+                                                             u64* __restrict__ desc,
+                                                             const u32* __restrict__ kp_img, size_t img_stride) {
 #pragma clang fp contract(off)
   const u32 k = blockIdx.x;
   const u32 di = threadIdx.x;
   if (k >= n) return;
+  if (kp_img) img += kp_img[k] * img_stride;
   const double2 p = corners[k];
   const int cx = (int)p.x, cy = (int)p.y;  // keypoints.h:213-214
   const double c = cs[k].x, s = cs[k].y;

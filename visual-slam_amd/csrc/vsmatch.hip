@@ -13,10 +13,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <exception>
 #include <cstring>
 #include <functional>
 #include <condition_variable>
@@ -1313,7 +1316,7 @@ static int orb_on_device(vsm_ctx* c, int width, int height, const double* corner
     for (size_t i = 0; i < n; i++) ang[i] = angles_in[i];  // computeDescriptors: kd.corner_angles as given
   } else if (rotate_features) {
     hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n + 3) / 4)), dim3(256), 0, c->stream, d_img, width,
-                       height, (u32)width, (const double2*)(d + o_xy), (u32)n, (int2*)(dd + o_mom));
+                       height, (u32)width, (const double2*)(d + o_xy), (u32)n, (int2*)(dd + o_mom), (const u32*)nullptr, (size_t)0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hd + o_mom, dd + o_mom, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1334,7 +1337,7 @@ static int orb_on_device(vsm_ctx* c, int width, int height, const double* corner
   HIP_TRY(hipMemcpyAsync(d + o_cs, h + o_cs, n * 16, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(orb_descriptor_kernel, dim3((u32)n), dim3(256), 0, c->stream, d_img, width, height,
                      (u32)width, (const double2*)(d + o_xy), (const double2*)(d + o_cs), (u32)n,
-                     (u64*)(dd + o_desc));
+                     (u64*)(dd + o_desc), (const u32*)nullptr, (size_t)0);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(hd + o_desc, dd + o_desc, n * DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1358,6 +1361,56 @@ static int orb_impl(vsm_ctx* c, const uint8_t* img, int width, int height, size_
   return orb_on_device(c, width, height, corners_xy, n, rotate_features, angles_in, angles_out, desc_out);
 }
 
+// The sequential pass of cv::goodFeaturesToTrack over the ordered candidates (key = value << 32 |
+// pixel index, descending): a candidate is kept unless an already kept one lies closer than
+// min_distance (grid of cells of cvRound(min_distance) pixels, 3 x 3 cells searched), until
+// max_corners are kept.  Resumable: feed() may be called again with the candidates that follow.
+struct MinDistancePass {
+  u32 w;
+  int cell = 1, gw = 0, gh = 0, max_corners;
+  double md2;
+  bool suppress, done = false;
+  std::vector<int> head, next;
+  std::vector<u32> kept;
+  std::vector<double> xy;
+  MinDistancePass(int width, int height, int max_corners_, double min_distance)
+      : w((u32)width), max_corners(max_corners_), md2(min_distance * min_distance), suppress(min_distance >= 1) {
+    if (suppress) {
+      cell = (int)std::lrint(min_distance);  // cvRound
+      gw = (width + cell - 1) / cell;
+      gh = (height + cell - 1) / cell;
+      head.assign((size_t)gw * gh, -1);
+    }
+  }
+  void feed(const u64* cand, size_t nc) {
+    for (size_t k = 0; k < nc && !done; k++) {
+      const u32 idx = (u32)cand[k];
+      const int y = (int)(idx / w), x = (int)(idx % w);
+      if (suppress) {
+        const int xc = x / cell, yc = y / cell;
+        const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+        bool good = true;
+        for (int yy = y1; yy <= y2 && good; yy++)
+          for (int xx = x1; xx <= x2 && good; xx++)
+            for (int m = head[(size_t)yy * gw + xx]; m >= 0; m = next[m]) {
+              const float ddx = (float)x - (float)(kept[m] % w), ddy = (float)y - (float)(kept[m] / w);
+              if (ddx * ddx + ddy * ddy < md2) {
+                good = false;
+                break;
+              }
+            }
+        if (!good) continue;
+        next.push_back(head[(size_t)yc * gw + xc]);
+        head[(size_t)yc * gw + xc] = (int)kept.size();
+        kept.push_back(idx);
+      }
+      xy.push_back((double)x);
+      xy.push_back((double)y);
+      if (max_corners > 0 && (int)(xy.size() / 2) == max_corners) done = true;
+    }
+  }
+};
+
 // cv::goodFeaturesToTrack on the image staged in c->image: per-pixel work on the device,
 // candidate ordering and the sequential minimum-distance pass on the host.
 static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, double quality,
@@ -1373,7 +1426,7 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
   HIP_TRY(hipMemsetAsync(d_misc, 0, 8, c->stream));
   const dim3 grid((u32)((width + 63) / 64), (u32)((height + 3) / 4)), block(256);
   hipLaunchKernelGGL(gftt_sobel_kernel, grid, block, 0, c->stream, (const uint8_t*)c->image.p, width, height,
-                     (u32)width, (float2*)(d + o_grad));
+                     (u32)width, (float2*)(d + o_grad), (size_t)0);
   hipLaunchKernelGGL(gftt_mineig_kernel, grid, block, 0, c->stream, (const float2*)(d + o_grad), width, height,
                      (float*)(d + o_eig), d_misc);
   hipLaunchKernelGGL(gftt_candidates_kernel, grid, block, 0, c->stream, (const float*)(d + o_eig), width, height,
@@ -1382,7 +1435,7 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
   // kernel sorts -- it reads the real count itself, so no host round trip is needed in between
   const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + GFTT_RANK_BLOCK - 1) / GFTT_RANK_BLOCK);
   hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks), dim3(GFTT_RANK_BLOCK), 0, c->stream, (const u64*)(d + o_cand),
-                     (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad));
+                     (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad), 0u);
   HIP_TRY(hipGetLastError());
   // one speculative download: the count and the first GFTT_FIRST_COPY ordered candidates
   constexpr size_t GFTT_FIRST_COPY = 4096;
@@ -1394,53 +1447,20 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
   const size_t nc = std::min<size_t>(((const u32*)hp)[1], n);
   if (nc == 0) return VSM_OK;
   const bool device_sorted = nc <= GFTT_RANK_SORT_MAX;
-  if (nc > GFTT_FIRST_COPY || !device_sorted) {
+  const size_t first = device_sorted ? std::min(nc, GFTT_FIRST_COPY) : 0;
+  MinDistancePass pass(width, height, max_corners, min_distance);
+  pass.feed((const u64*)(hp + 256), first);
+  if (!pass.done && nc > first) {  // the pass wants more candidates than the speculative copy held
     VSM_TRY(c->pin.reserve(256 + nc * 8));  // nothing is in flight here
     hp = (char*)c->pin.p;
     HIP_TRY(hipMemcpyAsync(hp + 256, d + (device_sorted ? o_grad : o_cand), nc * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    u64* cand = (u64*)(hp + 256);
+    // value descending, ties by the higher pixel address first (cv greaterThanPtr) = key descending
+    if (!device_sorted) std::sort(cand, cand + nc, std::greater<u64>());
+    pass.feed(cand + first, nc - first);
   }
-  u64* cand = (u64*)(hp + 256);
-  // value descending, ties by the higher pixel address first (cv greaterThanPtr) = key descending
-  if (!device_sorted) std::sort(cand, cand + nc, std::greater<u64>());
-  const u32 w = (u32)width;
-  if (min_distance >= 1) {
-    const int cell = (int)std::lrint(min_distance);  // cvRound
-    const int gw = (width + cell - 1) / cell, gh = (height + cell - 1) / cell;
-    std::vector<int> head((size_t)gw * gh, -1), next;
-    std::vector<u32> kept;
-    const double md2 = min_distance * min_distance;
-    for (size_t k = 0; k < nc; k++) {
-      const u32 idx = (u32)cand[k];
-      const int y = (int)(idx / w), x = (int)(idx % w);
-      const int xc = x / cell, yc = y / cell;
-      const int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
-      bool good = true;
-      for (int yy = y1; yy <= y2 && good; yy++)
-        for (int xx = x1; xx <= x2 && good; xx++)
-          for (int m = head[(size_t)yy * gw + xx]; m >= 0; m = next[m]) {
-            const float ddx = (float)x - (float)(kept[m] % w), ddy = (float)y - (float)(kept[m] / w);
-            if (ddx * ddx + ddy * ddy < md2) {
-              good = false;
-              break;
-            }
-          }
-      if (!good) continue;
-      next.push_back(head[(size_t)yc * gw + xc]);
-      head[(size_t)yc * gw + xc] = (int)kept.size();
-      kept.push_back(idx);
-      xy.push_back((double)x);
-      xy.push_back((double)y);
-      if (max_corners > 0 && (int)kept.size() == max_corners) break;
-    }
-  } else {
-    for (size_t k = 0; k < nc; k++) {
-      const u32 idx = (u32)cand[k];
-      xy.push_back((double)(idx % w));
-      xy.push_back((double)(idx / w));
-      if (max_corners > 0 && (int)(xy.size() / 2) == max_corners) break;
-    }
-  }
+  xy.swap(pass.xy);
   return VSM_OK;
 }
 
@@ -1819,6 +1839,260 @@ int vsm_bow_select_pairs(vsm_ctx* c, const int64_t* frame_id, size_t num_candida
     }
   *n_pairs = m;
   if (m > cap) return fail(VSM_ERR_CAPACITY, "%zu pairs, capacity %zu", m, cap);
+  return VSM_OK;
+ });
+}
+
+}  // extern "C"
+
+// ---- the detection + ORB front end over a whole set of images (sfm.cpp:1191-1201) --------------
+
+namespace {
+
+unsigned host_threads(size_t n_items) {
+  unsigned t = 8;
+  if (const char* e = getenv("VSM_HOST_THREADS")) {
+    const long v = strtol(e, nullptr, 10);
+    if (v >= 1 && v <= 64) t = (unsigned)v;
+  }
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw) t = std::min(t, hw);
+  return (unsigned)std::min<size_t>(std::max(1u, t), std::max<size_t>(n_items, 1));
+}
+
+// f(i) for i in [0, n) on host threads (the per-image host steps of the front end: packing rows,
+// the sequential minimum-distance pass, atan2 / cos / sin).  The first exception is rethrown here.
+template <class F>
+void parallel_items(size_t n, size_t min_per_thread, F&& f) {
+  const unsigned t = host_threads(n / std::max<size_t>(min_per_thread, 1));
+  if (t <= 1) {
+    for (size_t i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::mutex err_mu;
+  auto body = [&]() {
+    try {
+      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(err_mu);
+      if (!err) err = std::current_exception();
+      next.store(n);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned k = 1; k < t; k++) th.emplace_back(body);
+  body();
+  for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
+}
+
+constexpr size_t BATCH_DEVICE_BUDGET = (size_t)8 << 30;  // images + detector work areas of one chunk
+constexpr size_t BATCH_MAX_CHUNK = 16384;                // images per chunk (grid.z)
+constexpr size_t BATCH_FIRST_COPY = 4096;                // ordered candidates per image in the speculative download
+
+}  // namespace
+
+extern "C" {
+
+int vsm_detect_and_describe_batch(vsm_ctx* c, const uint8_t* const* imgs, size_t n_img, int width, int height, size_t pitch,
+                                  int num_features, int rotate_features, uint32_t* out_offsets, double* corners_out,
+                                  double* angles_out, uint64_t* desc_out, size_t cap, int keep_as_database) {
+ return no_throw([&]() -> int {
+  VSM_TRY(check_ctx(c));
+  if (!out_offsets) return fail(VSM_ERR_INVALID, "null out_offsets");
+  for (size_t i = 0; i <= n_img; i++) out_offsets[i] = 0;
+  if (num_features < 0) return fail(VSM_ERR_INVALID, "num_features must be >= 0");
+  if (keep_as_database && num_features == 0)
+    return fail(VSM_ERR_INVALID, "keep_as_database needs num_features > 0 (the database is sized before detection)");
+  if (n_img >= 0x7fffffffull / std::max(1, num_features)) return fail(VSM_ERR_INVALID, "too many images");
+  if (n_img && !imgs) return fail(VSM_ERR_INVALID, "null image list");
+  for (size_t i = 0; i < n_img; i++) VSM_TRY(check_image(imgs[i], width, height, pitch));
+  const bool want_out = corners_out || angles_out || desc_out;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  DeviceGuard g(c->device);
+  if (keep_as_database) {  // as vsm_db_upload: from here on the old database is gone
+    c->db = nullptr;
+    c->img_off.clear();
+    VSM_TRY(c->db_owned.reserve(std::max<size_t>(n_img * (size_t)num_features * DESC_BYTES, 256)));
+  }
+  if (n_img == 0) return keep_as_database ? set_db(c, c->db_owned.p, out_offsets, 0) : VSM_OK;
+
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t n = (size_t)width * height;
+  const size_t chunk = std::max<size_t>(1, std::min({n_img, BATCH_MAX_CHUNK, BATCH_DEVICE_BUDGET / (n * 21 + 8)}));
+  // detector work areas of a chunk: gradients (later the ordered candidates) | eig | candidates | (max key, count) pairs
+  const size_t o_grad = 0, o_eig = al(chunk * n * 8), o_cand = o_eig + al(chunk * n * 4), o_misc = o_cand + al(chunk * n * 8);
+  VSM_TRY(c->gftt.reserve(o_misc + al(chunk * 8)));
+  VSM_TRY(c->image.reserve(chunk * n));
+  VSM_TRY(c->pin_image.reserve(chunk * n));
+  char* d = (char*)c->gftt.p;
+  const uint8_t* d_img = (const uint8_t*)c->image.p;
+  const size_t first = std::min(n, BATCH_FIRST_COPY);
+  size_t total = 0;          // keypoints so far, over all chunks
+  bool overflow = false;     // the caller's arrays are too small: keep counting, stop writing
+  std::vector<std::vector<double>> xy(chunk);
+  std::vector<u64> more;     // an image whose pass needs more than the speculative copy
+  const size_t lds_sort_bytes = (size_t)std::min(GFTT_LDS_SORT_BLOCK, gftt_sort_size((u32)std::min<size_t>(n, GFTT_RANK_SORT_MAX))) * 8;
+  if (lds_sort_bytes > 48 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void*)gftt_lds_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort_bytes));
+
+  const bool trace = getenv("VSM_TRACE_BATCH") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "  batch: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  for (size_t i0 = 0; i0 < n_img; i0 += chunk) {
+    const size_t nb = std::min(chunk, n_img - i0);
+    // -- images up: rows packed to `width` into pinned memory by host threads, one copy
+    char* hi = (char*)c->pin_image.p;
+    parallel_items(nb, 1, [&](size_t b) {
+      const uint8_t* src = imgs[i0 + b];
+      char* dst = hi + b * n;
+      if (pitch == (size_t)width) memcpy(dst, src, n);
+      else
+        for (int y = 0; y < height; y++) memcpy(dst + (size_t)y * width, src + (size_t)y * pitch, (size_t)width);
+    });
+    lap("rows into pinned memory");
+    HIP_TRY(hipMemcpyAsync(c->image.p, hi, nb * n, hipMemcpyHostToDevice, c->stream));
+    // -- detection on the device, every image of the chunk in each launch
+    u32* d_misc = (u32*)(d + o_misc);
+    HIP_TRY(hipMemsetAsync(d_misc, 0, nb * 8, c->stream));
+    const dim3 grid((u32)((width + 63) / 64), (u32)((height + 3) / 4), (u32)nb), block(256);
+    hipLaunchKernelGGL(gftt_sobel_kernel, grid, block, 0, c->stream, d_img, width, height, (u32)width, (float2*)(d + o_grad), n);
+    hipLaunchKernelGGL(gftt_mineig_kernel, grid, block, 0, c->stream, (const float2*)(d + o_grad), width, height,
+                       (float*)(d + o_eig), d_misc);
+    hipLaunchKernelGGL(gftt_candidates_kernel, grid, block, 0, c->stream, (const float*)(d + o_eig), width, height,
+                       (const u32*)d_misc, 0.01, (u64*)(d + o_cand), d_misc + 1, (u32)n);
+    const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + GFTT_RANK_BLOCK - 1) / GFTT_RANK_BLOCK);
+    // order: one workgroup per image in LDS; the brute-force kernel only for images beyond its capacity
+    hipLaunchKernelGGL(gftt_lds_sort_kernel, dim3((u32)nb), dim3(1024), lds_sort_bytes, c->stream, (const u64*)(d + o_cand),
+                       (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad));
+    if (!gftt_lds_sorts((u32)std::min<size_t>(n, GFTT_RANK_SORT_MAX), (u32)n))  // small images: the padded size may not fit
+      hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks, 1, (u32)nb), dim3(GFTT_RANK_BLOCK), 0, c->stream,
+                         (const u64*)(d + o_cand), (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad), 1u);
+    HIP_TRY(hipGetLastError());
+    // -- one download: the (max key, count) pairs and the first ordered candidates of every image
+    const size_t h_cand = al(nb * 8);
+    VSM_TRY(c->pin.reserve(h_cand + nb * first * 8));
+    char* hp = (char*)c->pin.p;
+    HIP_TRY(hipMemcpyAsync(hp, d_misc, nb * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(hp + h_cand, first * 8, d + o_grad, n * 8, first * 8, nb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    lap("upload, detection, download");
+    // -- the sequential pass + the EDGE_THRESHOLD filter, images in parallel on host threads
+    std::vector<MinDistancePass> passes;
+    passes.reserve(nb);
+    for (size_t b = 0; b < nb; b++) passes.emplace_back(width, height, num_features, 8.0);
+    std::vector<uint8_t> unfinished(nb, 0);
+    const u32* h_misc = (const u32*)hp;
+    parallel_items(nb, 1, [&](size_t b) {
+      const size_t nc = std::min<size_t>(h_misc[2 * b + 1], n);
+      const bool device_sorted = nc <= GFTT_RANK_SORT_MAX;
+      const size_t have = device_sorted ? std::min(nc, first) : 0;
+      passes[b].feed((const u64*)(hp + h_cand) + b * first, have);
+      unfinished[b] = !passes[b].done && nc > have;
+      if (!unfinished[b]) {
+        xy[b].swap(passes[b].xy);
+        edge_filter(xy[b], width, height);
+      }
+    });
+    lap("minimum-distance pass");
+    for (size_t b = 0; b < nb; b++) {  // rare: fetch the image's whole candidate list
+      if (!unfinished[b]) continue;
+      const size_t nc = std::min<size_t>(h_misc[2 * b + 1], n);
+      const bool device_sorted = nc <= GFTT_RANK_SORT_MAX;
+      const size_t have = device_sorted ? std::min(nc, first) : 0;
+      more.resize(nc);
+      HIP_TRY(hipMemcpy(more.data(), d + (device_sorted ? o_grad : o_cand) + b * n * 8, nc * 8, hipMemcpyDeviceToHost));
+      if (!device_sorted) std::sort(more.begin(), more.end(), std::greater<u64>());
+      passes[b].feed(more.data() + have, nc - have);
+      xy[b].swap(passes[b].xy);
+      edge_filter(xy[b], width, height);
+    }
+    lap("unfinished passes");
+    size_t n_chunk = 0;
+    for (size_t b = 0; b < nb; b++) {
+      out_offsets[i0 + b] = (uint32_t)total + (uint32_t)n_chunk;
+      n_chunk += xy[b].size() / 2;
+    }
+    out_offsets[i0 + nb] = (uint32_t)(total + n_chunk);
+    if (total + n_chunk >= 0x7fffffffull) return fail(VSM_ERR_INVALID, "more than 2^31 keypoints");
+    if (want_out && total + n_chunk > cap) overflow = true;
+    const bool write_out = want_out && !overflow;
+    if (n_chunk && (write_out || keep_as_database)) {
+      // -- ORB: corners + image index per keypoint up, moments down, atan2 / cos / sin on host threads
+      // (the caller's libm, as the reference), (cos, sin) up, descriptors -- into the database or down
+      const size_t o_xy = 0, o_ki = al(n_chunk * 16), o_cs = o_ki + al(n_chunk * 4), up_bytes = o_cs + al(n_chunk * 16);
+      const size_t o_mom = 0, o_desc = al(n_chunk * 8), down_bytes = o_desc + n_chunk * DESC_BYTES;
+      VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
+      VSM_TRY(c->stage.reserve(up_bytes));
+      VSM_TRY(c->w_out.reserve(down_bytes));
+      char* h = (char*)c->pin.p;
+      char* hd = h + up_bytes;
+      char* ds = (char*)c->stage.p;
+      char* dd = (char*)c->w_out.p;
+      parallel_items(nb, 16, [&](size_t b) {
+        const size_t k = out_offsets[i0 + b] - total;
+        memcpy(h + o_xy + k * 16, xy[b].data(), xy[b].size() * 8);
+        u32* ki = (u32*)(h + o_ki) + k;
+        for (size_t i = 0; i < xy[b].size() / 2; i++) ki[i] = (u32)b;
+      });
+      lap("edge filter, corner lists");
+      HIP_TRY(hipMemcpyAsync(ds, h, o_cs, hipMemcpyHostToDevice, c->stream));  // corners and image indices
+      double* cs = (double*)(h + o_cs);
+      std::vector<double> ang_local;
+      double* ang = (write_out && angles_out) ? angles_out + total : nullptr;
+      if (!ang) {
+        ang_local.resize(n_chunk);
+        ang = ang_local.data();
+      }
+      if (rotate_features) {
+        hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n_chunk + 3) / 4)), dim3(256), 0, c->stream, d_img, width, height,
+                           (u32)width, (const double2*)(ds + o_xy), (u32)n_chunk, (int2*)(dd + o_mom),
+                           (const u32*)(ds + o_ki), n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(hd + o_mom, dd + o_mom, n_chunk * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        lap("moments");
+        const int32_t* mom = (const int32_t*)(hd + o_mom);
+        constexpr size_t SLAB = 4096;
+        parallel_items((n_chunk + SLAB - 1) / SLAB, 1, [&](size_t sl) {
+          for (size_t i = sl * SLAB; i < std::min(n_chunk, (sl + 1) * SLAB); i++) {
+            ang[i] = std::atan2((double)mom[2 * i + 1], (double)mom[2 * i]);  // keypoints.h:195
+            cs[2 * i] = std::cos(ang[i]);                                     // keypoints.h:219
+            cs[2 * i + 1] = std::sin(ang[i]);
+          }
+        });
+      } else {
+        for (size_t i = 0; i < n_chunk; i++) {
+          ang[i] = 0;  // keypoints.h:161
+          cs[2 * i] = std::cos(0.0);
+          cs[2 * i + 1] = std::sin(0.0);
+        }
+      }
+      lap("atan2, cos, sin");
+      HIP_TRY(hipMemcpyAsync(ds + o_cs, h + o_cs, n_chunk * 16, hipMemcpyHostToDevice, c->stream));
+      u64* d_desc = keep_as_database ? (u64*)((char*)c->db_owned.p + total * DESC_BYTES) : (u64*)(dd + o_desc);
+      hipLaunchKernelGGL(orb_descriptor_kernel, dim3((u32)n_chunk), dim3(256), 0, c->stream, d_img, width, height, (u32)width,
+                         (const double2*)(ds + o_xy), (const double2*)(ds + o_cs), (u32)n_chunk, d_desc,
+                         (const u32*)(ds + o_ki), n);
+      HIP_TRY(hipGetLastError());
+      if (write_out && desc_out)
+        HIP_TRY(hipMemcpyAsync(hd + o_desc, d_desc, n_chunk * DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (write_out && desc_out) memcpy(desc_out + 4 * total, hd + o_desc, n_chunk * DESC_BYTES);
+      if (write_out && corners_out) memcpy(corners_out + 2 * total, h + o_xy, n_chunk * 16);
+      lap("descriptors, copies out");
+    }
+    total += n_chunk;
+  }
+  if (overflow) return fail(VSM_ERR_CAPACITY, "%zu keypoints need more than cap=%zu (out_offsets holds the counts)", total, cap);
+  if (keep_as_database) return set_db(c, c->db_owned.p, out_offsets, n_img);
   return VSM_OK;
  });
 }

@@ -30,7 +30,7 @@ SYMBOLS = (
     "vsm_set_variant", "vsm_accept_limit",
     "vsm_match_landmarks",
     "vsm_orb_describe", "vsm_orb_angles", "vsm_orb_descriptors",
-    "vsm_detect_keypoints", "vsm_good_features_to_track", "vsm_detect_and_describe",
+    "vsm_detect_keypoints", "vsm_good_features_to_track", "vsm_detect_and_describe", "vsm_detect_and_describe_batch",
     "vsm_voc_upload", "vsm_bow_words",
     "vsm_bowdb_upload", "vsm_bowdb_query", "vsm_bow_select_pairs",
 )
@@ -109,6 +109,8 @@ def lib():
             L.vsm_detect_keypoints.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, _vp, _sz, C.POINTER(_sz)]
             L.vsm_good_features_to_track.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, C.c_double, C.c_double,
                                                      _vp, _sz, C.POINTER(_sz)]
+            L.vsm_detect_and_describe_batch.argtypes = [_vp, _vp, _sz, C.c_int, C.c_int, _sz, C.c_int, C.c_int, _vp, _vp, _vp,
+                                                        _vp, _sz, C.c_int]
             L.vsm_detect_and_describe.argtypes = [_vp, _vp, C.c_int, C.c_int, _sz, C.c_int, C.c_int, _vp, _vp, _vp,
                                                   _sz, C.POINTER(_sz)]
             L.vsm_voc_upload.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]
@@ -346,6 +348,44 @@ class Matcher:
                                              _ptr(desc), cap, C.byref(n)))
         k = n.value
         return xy[:k].copy(), ang[:k].copy(), desc[:k].copy()
+
+    def detect_and_describe_batch(self, images, num_features: int, rotate_features: bool = True,
+                                  keep_as_database: bool = False, want=("corners", "angles", "descriptors")):
+        """The loop of detect_keypoints(), sfm.cpp:1191-1201, in one call: `images` = equally sized
+        uint8 images (a list of 2-D arrays or one 3-D array) -> (offsets uint32[n+1], corners f64[t,2],
+        angles f64[t], descriptors u64[t,4]); arrays not named in `want` come back as None.
+        keep_as_database: the descriptors also become the context's database (as after db_upload)."""
+        imgs = [self._image(im) for im in images]
+        n_img = len(imgs)
+        if n_img == 0:
+            h = w = pitch = 1
+        else:
+            h, w = imgs[0].shape
+            pitch = imgs[0].strides[0]
+            for im in imgs:
+                if im.shape != (h, w) or im.strides[0] != pitch:
+                    raise ValueError("the images of a batch must have one size and pitch")
+        ptrs = (C.c_void_p * max(n_img, 1))(*[im.ctypes.data for im in imgs])
+        offsets = np.zeros(n_img + 1, dtype=np.uint32)
+        cap = n_img * (num_features if num_features > 0 else 4096)
+        while True:
+            xy = np.zeros((max(cap, 1), 2), dtype=np.float64) if "corners" in want else None
+            ang = np.zeros(max(cap, 1), dtype=np.float64) if "angles" in want else None
+            desc = np.zeros((max(cap, 1), 4), dtype=np.uint64) if "descriptors" in want else None
+            rc = lib().vsm_detect_and_describe_batch(self._h, ptrs, n_img, w, h, pitch, int(num_features),
+                                                     1 if rotate_features else 0, _ptr(offsets),
+                                                     _ptr(xy) if xy is not None else None, _ptr(ang) if ang is not None else None,
+                                                     _ptr(desc) if desc is not None else None, cap, 1 if keep_as_database else 0)
+            if rc == VSM_ERR_CAPACITY and int(offsets[-1]) > cap:
+                cap = int(offsets[-1])
+                continue
+            _check(rc)
+            break
+        t = int(offsets[-1])
+        if keep_as_database:
+            self._offsets = offsets.copy()
+        return (offsets, xy[:t].copy() if xy is not None else None, ang[:t].copy() if ang is not None else None,
+                desc[:t].copy() if desc is not None else None)
 
     def orb_descriptors(self, img, corners_xy, angles) -> np.ndarray:
         """visnav::computeDescriptors with caller-given angles (keypoints.h:203-237)."""
