@@ -1950,7 +1950,7 @@ int vsm_detect_and_describe_batch(vsm_ctx* c, const uint8_t* const* imgs, size_t
     const size_t nb = std::min(chunk, n_img - i0);
     // -- images up: rows packed to `width` into pinned memory by host threads, one copy
     char* hi = (char*)c->pin_image.p;
-    parallel_items(nb, 1, [&](size_t b) {
+    parallel_items(nb, 4, [&](size_t b) {
       const uint8_t* src = imgs[i0 + b];
       char* dst = hi + b * n;
       if (pitch == (size_t)width) memcpy(dst, src, n);
@@ -1990,7 +1990,7 @@ int vsm_detect_and_describe_batch(vsm_ctx* c, const uint8_t* const* imgs, size_t
     for (size_t b = 0; b < nb; b++) passes.emplace_back(width, height, num_features, 8.0);
     std::vector<uint8_t> unfinished(nb, 0);
     const u32* h_misc = (const u32*)hp;
-    parallel_items(nb, 1, [&](size_t b) {
+    parallel_items(nb, 4, [&](size_t b) {
       const size_t nc = std::min<size_t>(h_misc[2 * b + 1], n);
       const bool device_sorted = nc <= GFTT_RANK_SORT_MAX;
       const size_t have = device_sorted ? std::min(nc, first) : 0;
