@@ -162,6 +162,25 @@ def test_batch_front_end_into_the_database(m):
     assert np.array_equal(lists, o.match(desc2[:off2[1]], desc2[off2[1]:], 90, 1.1))
 
 
+def test_batch_front_end_in_several_chunks(m):
+    """More images than one chunk of device work areas holds (forced by VSM_BATCH_CHUNK: 3 per chunk
+    instead of ~1000): same results, same kept database."""
+    imgs = _batch_images()
+    want = m.detect_and_describe_batch(imgs, 700, True)
+    os.environ["VSM_BATCH_CHUNK"] = "3"
+    try:
+        got = m.detect_and_describe_batch(imgs, 700, True, keep_as_database=True)
+    finally:
+        del os.environ["VSM_BATCH_CHUNK"]
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    off, desc = got[0], got[3]
+    pairs = np.array([[0, 1], [4, 2], [7, 5], [3, 6], [5, 7]], np.uint32)
+    offs, lists = m.match_pairs(pairs, 80, 1.2)
+    for k, (i, j) in enumerate(pairs.tolist()):
+        assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])],
+                              binding.port().match(desc[off[i]:off[i + 1]], desc[off[j]:off[j + 1]], 80, 1.2))
+
+
 def test_batch_front_end_errors_and_capacity(m):
     import ctypes as C
     L = vsm.matcher.lib()

@@ -1921,7 +1921,11 @@ int vsm_detect_and_describe_batch(vsm_ctx* c, const uint8_t* const* imgs, size_t
 
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t n = (size_t)width * height;
-  const size_t chunk = std::max<size_t>(1, std::min({n_img, BATCH_MAX_CHUNK, BATCH_DEVICE_BUDGET / (n * 21 + 8)}));
+  size_t chunk = std::max<size_t>(1, std::min({n_img, BATCH_MAX_CHUNK, BATCH_DEVICE_BUDGET / (n * 21 + 8)}));
+  if (const char* e = getenv("VSM_BATCH_CHUNK")) {  // tests: several chunks without thousands of images
+    const long v = strtol(e, nullptr, 10);
+    if (v >= 1) chunk = std::min(chunk, (size_t)v);
+  }
   // detector work areas of a chunk: gradients (later the ordered candidates) | eig | candidates | (max key, count) pairs
   const size_t o_grad = 0, o_eig = al(chunk * n * 8), o_cand = o_eig + al(chunk * n * 4), o_misc = o_cand + al(chunk * n * 8);
   VSM_TRY(c->gftt.reserve(o_misc + al(chunk * 8)));
