@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the batched matcher against the oracle (GPU box, through gpurun).
 
-    python3 tools/soak_fuzz.py [seconds=240] [seed=1]
+    python3 tools/soak_fuzz.py [seconds=240] [seed=1] [single]
 
 Each case draws a database (uniform / ragged image sizes incl. empty images; planted overlap,
 real-ORB statistics or heavy duplicates), an accept test (threshold, ratio), a pair list (random
 ordered pairs, both orientations, repeats, self pairs) and an experiment-knob setting, runs
 vsm_match_pairs and compares EVERY pair's list with the oracle port (16 threads over pairs).
 Prints one line per case and a summary; exits 1 at the first difference, naming the case.
+With `single`: vsm_match_pair and vsm_nn2 on random pairs of sets instead (latency shapes, train splits).
 Not a test (the -m gpu suite holds the fixed cases): a tool for hunting rare cases after a change
 to the scan, the pruned backward pass or the refinement.
 """
@@ -64,9 +65,58 @@ def make_database(rng, real, case):
     return np.ascontiguousarray(db, dtype=np.uint64).reshape(-1, 4), off.astype(np.uint32), kind
 
 
+def single_pairs(budget, seed):
+    """vsm_match_pair and vsm_nn2 (host pointers; the latency shapes and train splits) on random pairs of sets."""
+    rng = np.random.default_rng(seed)
+    real = real_pool()
+    m = matcher.Matcher(0)
+    o = binding.port()
+    variants = [0, 0, 0, 1, 4, 8, 0x0301, 0x0308, 0x0208, 0x1708, POPCOUNT | 8, POPCOUNT | 1, TILE64 | 8, TILE128 | 8, TILE256 | 8]
+    t_end = time.time() + budget
+    case = 0
+    while time.time() < t_end:
+        case += 1
+        hi = int(rng.choice([40, 300, 2100, 6000]))
+        n1, n2 = (int(v) for v in rng.integers(0, hi + 1, 2))
+        kind = rng.choice(["planted", "real", "dups"])
+        if kind == "planted":
+            a, b = synth.orb_like_pair(max(n1, 1), max(n2, 1), seed=seed * 100_000 + case, match_frac=float(rng.uniform(0, 1)),
+                                       dup_frac=float(rng.uniform(0, 0.3)), confuse_frac=float(rng.uniform(0, 0.3)))
+        elif kind == "real":
+            lv = (int(rng.integers(4, 7)),)
+            a = real[rng.integers(0, len(real), max(n1, 1))] ^ synth.flip_masks(max(n1, 1), 5, case, levels=lv)
+            b = real[rng.integers(0, len(real), max(n2, 1))] ^ synth.flip_masks(max(n2, 1), 6, case, levels=lv)
+        else:
+            base = synth.random_descriptors(8, seed=case)
+            a = base[rng.integers(0, 8, max(n1, 1))] ^ synth.flip_masks(max(n1, 1), 7, case, levels=(8,))
+            b = base[rng.integers(0, 8, max(n2, 1))] ^ synth.flip_masks(max(n2, 1), 8, case, levels=(8,))
+        a, b = np.ascontiguousarray(a[:n1]), np.ascontiguousarray(b[:n2])
+        thr, ratio = (70, 1.2) if rng.random() < 0.5 else (int(rng.integers(1, 301)), float(rng.uniform(0.5, 3.0)))
+        variant = int(rng.choice(variants))
+        m.set_variant(variant)
+        try:
+            got = m.match(a, b, thr, ratio)
+            nn = m.nn2(a, b) if n1 and n2 and rng.random() < 0.5 else None
+        finally:
+            m.set_variant(0)
+        ok = np.array_equal(got, o.match(a, b, thr, ratio))
+        if ok and nn is not None:
+            ok = all(np.array_equal(g, w) for g, w in zip(nn, o.nn2(a, b)))
+        line = f"case {case} seed {seed}: {kind} {n1} x {n2}, thr {thr} ratio {ratio:.4f}, variant {variant:#x}: {len(got)} matches"
+        if not ok:
+            print(line + " -- DIFFERENT", flush=True)
+            return 1
+        if case % 200 == 0:
+            print(line, flush=True)
+    print(f"soak (single pairs): {case} cases, all equal to the oracle", flush=True)
+    return 0
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "single":
+        return single_pairs(budget, seed)
     rng = np.random.default_rng(seed)
     real = real_pool()
     m = matcher.Matcher(0)
