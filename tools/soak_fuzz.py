@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the batched matcher against the oracle (GPU box, through gpurun).
 
-    python3 tools/soak_fuzz.py [seconds=240] [seed=1] [single]
+    python3 tools/soak_fuzz.py [seconds=240] [seed=1] [single | frontend]
 
 Each case draws a database (uniform / ragged image sizes incl. empty images; planted overlap,
 real-ORB statistics or heavy duplicates), an accept test (threshold, ratio), a pair list (random
@@ -9,6 +9,7 @@ ordered pairs, both orientations, repeats, self pairs) and an experiment-knob se
 vsm_match_pairs and compares EVERY pair's list with the oracle port (16 threads over pairs).
 Prints one line per case and a summary; exits 1 at the first difference, naming the case.
 With `single`: vsm_match_pair and vsm_nn2 on random pairs of sets instead (latency shapes, train splits).
+With `frontend`: vsm_detect_and_describe_batch on random image sets against the oracle's detector + ORB.
 Not a test (the -m gpu suite holds the fixed cases): a tool for hunting rare cases after a change
 to the scan, the pruned backward pass or the refinement.
 """
@@ -112,9 +113,75 @@ def single_pairs(budget, seed):
     return 0
 
 
+def random_image(rng, w, h):
+    kind = rng.choice(["texture", "noise", "blocks", "gradient", "flat", "checker"], p=[0.35, 0.15, 0.2, 0.1, 0.05, 0.15])
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w)).astype(np.uint8)
+    if kind == "flat":
+        return np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+    if kind == "gradient":
+        yy, xx = np.indices((h, w))
+        return ((xx * int(rng.integers(1, 4)) + yy * int(rng.integers(0, 3))) % 256).astype(np.uint8)
+    if kind == "checker":  # exactly equal eigenvalues: the tie order of the candidates matters
+        yy, xx = np.indices((h, w))
+        c = int(rng.integers(3, 12))
+        return ((yy // c + xx // c) % 2 * int(rng.integers(60, 256))).astype(np.uint8)
+    c = int(rng.integers(2, 9))
+    a = rng.integers(0, 256, size=(h // c + 2, w // c + 2)).astype(np.float64)
+    a = np.kron(a, np.ones((c, c)))[:h, :w]
+    if kind == "texture":
+        a = (a + np.roll(a, 1, 0) + np.roll(a, 1, 1) + rng.integers(0, 40, size=(h, w))) / 3.2
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
+def front_end(budget, seed):
+    """vsm_detect_and_describe_batch on random image sets against the oracle's detector + ORB, image by image."""
+    rng = np.random.default_rng(seed)
+    m = matcher.Matcher(0)
+    o = binding.port()
+    pool = ThreadPoolExecutor(16)
+    t_end = time.time() + budget
+    case = n_images = n_kp = 0
+    while time.time() < t_end:
+        case += 1
+        w, h = int(rng.integers(40, 801)), int(rng.integers(40, 601))
+        n_img = int(rng.integers(1, 13))
+        pad = int(rng.integers(0, 9))
+        imgs = [random_image(rng, w + pad, h)[:, :w] if pad else random_image(rng, w, h) for _ in range(n_img)]
+        nf = int(rng.choice([0, 1, 50, 500, 1500, 4000]))
+        rot = bool(rng.random() < 0.8)
+        if rng.random() < 0.3:
+            os.environ["VSM_BATCH_CHUNK"] = str(int(rng.integers(1, 5)))
+        try:
+            off, xy, ang, desc = m.detect_and_describe_batch(imgs, nf, rot)
+        finally:
+            os.environ.pop("VSM_BATCH_CHUNK", None)
+
+        def check(k):
+            im = np.ascontiguousarray(imgs[k])
+            oxy = o.detect_keypoints(im, nf)
+            oa, od = o.orb_describe(im, oxy, rot)
+            sl = slice(int(off[k]), int(off[k + 1]))
+            return np.array_equal(xy[sl], oxy) and np.array_equal(ang[sl], oa) and np.array_equal(desc[sl], od)
+
+        ok = list(pool.map(check, range(n_img)))
+        n_images += n_img
+        n_kp += int(off[-1])
+        line = f"case {case} seed {seed}: {n_img} images {w} x {h} (pitch {w + pad}), num_features {nf}, rotate {rot}: {int(off[-1])} keypoints"
+        if not all(ok):
+            print(line + f" -- DIFFERENT at images {[k for k, v in enumerate(ok) if not v]}", flush=True)
+            return 1
+        if case % 20 == 0:
+            print(line, flush=True)
+    print(f"soak (front end): {case} cases, {n_images} images, {n_kp} keypoints, all equal to the oracle", flush=True)
+    return 0
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "frontend":
+        return front_end(budget, seed)
     if len(sys.argv) > 3 and sys.argv[3] == "single":
         return single_pairs(budget, seed)
     rng = np.random.default_rng(seed)
