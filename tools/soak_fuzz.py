@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential soak of the batched matcher against the oracle (GPU box, through gpurun).
 
-    python3 tools/soak_fuzz.py [seconds=240] [seed=1] [single | frontend]
+    python3 tools/soak_fuzz.py [seconds=240] [seed=1] [single | frontend | landmarks | bow]
 
 Each case draws a database (uniform / ragged image sizes incl. empty images; planted overlap,
 real-ORB statistics or heavy duplicates), an accept test (threshold, ratio), a pair list (random
@@ -10,6 +10,7 @@ vsm_match_pairs and compares EVERY pair's list with the oracle port (16 threads 
 Prints one line per case and a summary; exits 1 at the first difference, naming the case.
 With `single`: vsm_match_pair and vsm_nn2 on random pairs of sets instead (latency shapes, train splits).
 With `frontend`: vsm_detect_and_describe_batch on random image sets against the oracle's detector + ORB.
+With `landmarks` / `bow`: vsm_match_landmarks / the BoW database entry points against their oracles.
 Not a test (the -m gpu suite holds the fixed cases): a tool for hunting rare cases after a change
 to the scan, the pruned backward pass or the refinement.
 """
@@ -177,9 +178,92 @@ def front_end(budget, seed):
     return 0
 
 
+def landmarks(budget, seed):
+    """vsm_match_landmarks (find_matches_landmarks, vo_utils.h:95-187) on random frames against the oracle."""
+    rng = np.random.default_rng(seed)
+    m = matcher.Matcher(0)
+    o = binding.port()
+    t_end = time.time() + budget
+    case = n_matches = 0
+    while time.time() < t_end:
+        case += 1
+        nk, npj = int(rng.integers(0, 2500)), int(rng.integers(0, 4000))
+        radius = float(rng.choice([0.0, 3.0, 5.0, 20.0, 20.5, 50.0, 1000.0]))
+        f = synth.landmark_frame(nk, npj, seed * 100_000 + case, radius=max(radius, 1.0), max_obs=int(rng.integers(1, 12)),
+                                 lattice=bool(rng.random() < 0.4))
+        thr, ratio = (70, 1.2) if rng.random() < 0.5 else (int(rng.integers(1, 301)), float(rng.uniform(0.5, 3.0)))
+        got = m.match_landmarks(*f, radius, thr, ratio)
+        want = o.match_landmarks(*f, radius, thr, ratio)
+        n_matches += len(want)
+        line = f"case {case} seed {seed}: {nk} keypoints, {npj} landmarks, radius {radius}, thr {thr} ratio {ratio:.4f}: {len(want)} matches"
+        if not np.array_equal(got, want):
+            print(line + " -- DIFFERENT", flush=True)
+            return 1
+        if case % 200 == 0:
+            print(line, flush=True)
+    print(f"soak (landmarks): {case} cases, {n_matches} matches, all equal to the oracle", flush=True)
+    return 0
+
+
+def bow_database(budget, seed):
+    """vsm_bowdb_upload / vsm_bowdb_query / vsm_bow_select_pairs on random BoW vectors against the oracle's
+    BowDatabase (scores bit for bit, order by (score, image index): tests/test_gpu_bowdb.py::check_query)."""
+    from tests.test_gpu_bowdb import check_query, oracle_db
+    rng = np.random.default_rng(seed)
+    m = matcher.Matcher(0)
+    t_end = time.time() + budget
+    case = n_q = 0
+    while time.time() < t_end:
+        case += 1
+        n_img = int(rng.integers(1, 400))
+        n_words = int(rng.choice([5, 50, 2000, 100000]))
+        per = int(rng.integers(1, min(n_words, 300) + 1))
+        off, words, values = synth.bow_vectors(n_img, n_words, per, seed=seed * 100_000 + case, window=int(rng.integers(1, 12)),
+                                               share_frac=float(rng.uniform(0, 1)))
+        coarse = bool(rng.random() < 0.4)
+        if coarse:  # coarse values: equal scores everywhere
+            values = np.round(values * 8) / 8 + 0.125
+        vecs = [(words[off[i]:off[i + 1]], values[off[i]:off[i + 1]]) for i in range(n_img)]
+        m.bowdb_upload((off, words, values))
+        k = int(rng.choice([1, 4, 25, 64, 65, 200]))
+        qs = rng.integers(0, n_img, size=min(n_img, 12))
+        lim = rng.integers(0, n_img + 1, size=len(qs)) if rng.random() < 0.5 else None
+        res = m.bowdb_query([list(zip(vecs[q][0].tolist(), vecs[q][1].tolist())) for q in qs], k, db_limit=lim)
+        for qi, (q, (idx, score)) in enumerate(zip(qs, res)):
+            n_db = n_img if lim is None else int(lim[qi])
+            try:
+                check_query(oracle_db(vecs, n_db), n_db, vecs[q], k, idx, score)
+            except AssertionError:
+                print(f"case {case} seed {seed}: {n_img} images, {n_words} words, {per} per image, k {k}, query {q}, limit {n_db} -- DIFFERENT", flush=True)
+                raise
+        n_q += len(qs)
+        # the pair selection of match_bow (sfm.cpp:1366-1392): image i against the images before it, stereo partners
+        # skipped.  Which of several EQUAL scores make the cut is open in the reference (std::partial_sort; one
+        # shared word with the smaller weight on the query's side gives equal scores), so the list is checked
+        # against the library's own queries with limit i -- which check_query above holds to the oracle
+        nc = int(rng.choice([1, 7, 25]))
+        frames = np.arange(n_img) // 2
+        got = m.bow_select_pairs(frames, nc)
+        allq = m.bowdb_query((off, words, values), nc, db_limit=np.arange(n_img))
+        want = [(i, int(j)) for i, (idx, _) in enumerate(allq) for j in idx if frames[i] != frames[int(j)]]
+        if [tuple(p) for p in got.tolist()] != want:
+            print(f"case {case} seed {seed}: {n_img} images, {n_words} words, {per} per image: select_pairs({nc}) -- DIFFERENT", flush=True)
+            return 1
+        for i in rng.integers(0, n_img, size=4):
+            check_query(oracle_db(vecs, int(i)), int(i), vecs[i], nc, *allq[i])
+        if case % 50 == 0:
+            print(f"case {case} seed {seed}: {n_img} images, {n_words} words, {per} per image, k {k}: ok, {len(got)} pairs selected", flush=True)
+    print(f"soak (BoW database): {case} cases, {n_q} queries, all equal to the oracle", flush=True)
+    return 0
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "landmarks":
+        return landmarks(budget, seed)
+    if len(sys.argv) > 3 and sys.argv[3] == "bow":
+        return bow_database(budget, seed)
     if len(sys.argv) > 3 and sys.argv[3] == "frontend":
         return front_end(budget, seed)
     if len(sys.argv) > 3 and sys.argv[3] == "single":
