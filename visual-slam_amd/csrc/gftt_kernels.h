@@ -33,68 +33,90 @@ __device__ __forceinline__ float key_float(u32 k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// grad[y * w + x] = (Dx, Dy): Sobel 3x3 scaled by 1 / (4 * 3 * 255) as cornerMinEigenVal
-// scales it for 8-bit input, block size 3, aperture 3.
-__global__ __launch_bounds__(256) void gftt_sobel_kernel(const uint8_t* __restrict__ img, int w, int h, u32 pitch,
-                                                         float2* __restrict__ grad, size_t img_stride) {
+// eig = minimum eigenvalue of the 3x3-summed covariance matrix of the image gradient
+// (cv::cornerMinEigenVal for 8-bit input, block size 3, aperture 3); *max_key = float_key(max eig)
+// over the image (zero-initialised by the host).  A workgroup produces a 64 x 16 tile of `eig`:
+//  1. the gradient (Dx, Dy) of every pixel of the tile and its one-pixel halo, once: Sobel 3x3 scaled by
+//     1 / (4 * 3 * 255) -- Dx: row filter [-1 0 1] (exact), column filter [f1 f0 f1]; Dy the
+//     transpose -- with BORDER_REFLECT_101, evaluated at the REFLECTED coordinate where the halo leaves
+//     the image (that is the gradient the box sum reads there); its three products Dx Dx, Dx Dy, Dy Dy
+//     (float) go to LDS as doubles;
+//  2. the horizontal sums of three, left to right from 0.0 (double);
+//  3. the vertical sums (top + middle) + bottom (double), then a = (float)sxx / 2, b = (float)sxy,
+//     c = (float)syy / 2, eig = (a + c) - sqrt((a - c)^2 + b^2) in float, correctly rounded sqrt.
+// Operation for operation what the checker does per pixel (products and sums in float with contraction
+// off, box sums in double in this order), so the same bits.  (Round 1's form -- a Sobel kernel writing
+// the gradient image and a thread-per-pixel kernel forming all nine products of its window again, 27
+// float -> double conversions and 27 double additions per pixel, 386 instructions per wave -- took
+// 3.9 + 19 us per 752 x 480 image; this one kernel replaces both.)
+constexpr int GFTT_TILE_W = 64, GFTT_TILE_H = 16;
+__global__ __launch_bounds__(256) void gftt_sobel_mineig_kernel(const uint8_t* __restrict__ img, int w, int h, u32 pitch,
+                                                                float* __restrict__ eig, u32* __restrict__ max_key,
+                                                                size_t img_stride) {
 #pragma clang fp contract(off)
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
-  img += blockIdx.z * img_stride;
-  grad += blockIdx.z * ((size_t)w * h);
-  const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = 2.0f * f1;
-  const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
-  const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * pitch;
-  const uint8_t* r1 = img + (size_t)y * pitch;
-  const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * pitch;
-  const float a00 = r0[xm], a01 = r0[x], a02 = r0[xp];
-  const float a10 = r1[xm], a12 = r1[xp];
-  const float a20 = r2[xm], a21 = r2[x], a22 = r2[xp];
-  // Dx: row filter [-1 0 1] (exact), column filter [f1 f0 f1]
-  const float d0 = a02 - a00, d1 = a12 - a10, d2 = a22 - a20;
-  const float dxa = d1 * f0, dxb = (d0 + d2) * f1;
-  // Dy: row filter [f1 f0 f1], column filter [-1 0 1]
-  const float ta = a01 * f0, tb = (a00 + a02) * f1, ba = a21 * f0, bb = (a20 + a22) * f1;
-  const float top = ta + tb, bot = ba + bb;
-  grad[(size_t)y * w + x] = make_float2(dxa + dxb, bot - top);
-}
-
-// eig = minimum eigenvalue of the 3x3-summed covariance matrix (cv::cornerMinEigenVal);
-// *max_key = float_key(max eig) over the image (zero-initialised by the host).
-__global__ __launch_bounds__(256) void gftt_mineig_kernel(const float2* __restrict__ grad, int w, int h,
-                                                          float* __restrict__ eig, u32* __restrict__ max_key) {
-#pragma clang fp contract(off)
+  constexpr int PW = GFTT_TILE_W + 2, PH = GFTT_TILE_H + 2;
+  __shared__ double prod[3][PH][PW];           // pxx, pxy, pyy of the tile and its halo
+  __shared__ double rows[3][PH][GFTT_TILE_W];  // their horizontal sums of three
   __shared__ u32 wave_max[4];
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  grad += blockIdx.z * ((size_t)w * h);
+  img += blockIdx.z * img_stride;
   eig += blockIdx.z * ((size_t)w * h);
   max_key += 2 * blockIdx.z;
-  u32 key = 0;
-  if (x < w && y < h) {
-    double cxx[3], cxy[3], cyy[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const float2* row = grad + (size_t)reflect101(y + j - 1, h) * w;
-      double rxx = 0, rxy = 0, ryy = 0;
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const float2 g = row[reflect101(x + i - 1, w)];
-        const float pxx = g.x * g.x, pxy = g.x * g.y, pyy = g.y * g.y;
-        rxx += (double)pxx;
-        rxy += (double)pxy;
-        ryy += (double)pyy;
-      }
-      cxx[j] = rxx;
-      cxy[j] = rxy;
-      cyy[j] = ryy;
+  const int X0 = blockIdx.x * GFTT_TILE_W, Y0 = blockIdx.y * GFTT_TILE_H;
+  const float f1 = (float)(1.0 / (4.0 * 3.0 * 255.0)), f0 = 2.0f * f1;
+  for (int cell = threadIdx.x; cell < PH * PW; cell += 256) {
+    const int ty = cell / PW, tx = cell - ty * PW;
+    const int cx = X0 - 1 + tx, cy = Y0 - 1 + ty;
+    float pxx = 0.0f, pxy = 0.0f, pyy = 0.0f;
+    if (cx <= w && cy <= h) {  // cells further out serve no pixel of the image
+      const int x = reflect101(cx, w), y = reflect101(cy, h);
+      const int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+      const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * pitch;
+      const uint8_t* r1 = img + (size_t)y * pitch;
+      const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * pitch;
+      const float a00 = r0[xm], a01 = r0[x], a02 = r0[xp];
+      const float a10 = r1[xm], a12 = r1[xp];
+      const float a20 = r2[xm], a21 = r2[x], a22 = r2[xp];
+      const float d0 = a02 - a00, d1 = a12 - a10, d2 = a22 - a20;
+      const float dxa = d1 * f0, dxb = (d0 + d2) * f1;
+      const float ta = a01 * f0, tb = (a00 + a02) * f1, ba = a21 * f0, bb = (a20 + a22) * f1;
+      const float top = ta + tb, bot = ba + bb;
+      const float gx = dxa + dxb, gy = bot - top;
+      pxx = gx * gx;
+      pxy = gx * gy;
+      pyy = gy * gy;
     }
-    const double sxx = (cxx[0] + cxx[1]) + cxx[2], sxy = (cxy[0] + cxy[1]) + cxy[2], syy = (cyy[0] + cyy[1]) + cyy[2];
-    const float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-    const float amc = a - c;
-    const float t1 = amc * amc, t2 = b * b;
-    const float e = (a + c) - sqrtf(t1 + t2);
-    eig[(size_t)y * w + x] = e;
-    key = float_key(e);
+    prod[0][ty][tx] = (double)pxx;
+    prod[1][ty][tx] = (double)pxy;
+    prod[2][ty][tx] = (double)pyy;
+  }
+  __syncthreads();
+  for (int cell = threadIdx.x; cell < PH * GFTT_TILE_W; cell += 256) {
+    const int r = cell / GFTT_TILE_W, c = cell - r * GFTT_TILE_W;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      double s = 0;
+      s += prod[k][r][c];
+      s += prod[k][r][c + 1];
+      s += prod[k][r][c + 2];
+      rows[k][r][c] = s;
+    }
+  }
+  __syncthreads();
+  u32 key = 0;
+  for (int o = threadIdx.x; o < GFTT_TILE_H * GFTT_TILE_W; o += 256) {
+    const int r = o / GFTT_TILE_W, c = o - r * GFTT_TILE_W;
+    const int x = X0 + c, y = Y0 + r;
+    if (x < w && y < h) {
+      const double sxx = (rows[0][r][c] + rows[0][r + 1][c]) + rows[0][r + 2][c];
+      const double sxy = (rows[1][r][c] + rows[1][r + 1][c]) + rows[1][r + 2][c];
+      const double syy = (rows[2][r][c] + rows[2][r + 1][c]) + rows[2][r + 2][c];
+      const float a = (float)sxx * 0.5f, b = (float)sxy, cc = (float)syy * 0.5f;
+      const float amc = a - cc;
+      const float t1 = amc * amc, t2 = b * b;
+      const float e = (a + cc) - sqrtf(t1 + t2);
+      eig[(size_t)y * w + x] = e;
+      key = max(key, float_key(e));
+    }
   }
   for (int o = 32; o > 0; o >>= 1) key = max(key, (u32)__shfl_xor((int)key, o));
   if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = key;

@@ -1425,10 +1425,9 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
   u32* d_misc = (u32*)(d + o_misc);  // [0] max key, [1] candidate count
   HIP_TRY(hipMemsetAsync(d_misc, 0, 8, c->stream));
   const dim3 grid((u32)((width + 63) / 64), (u32)((height + 3) / 4)), block(256);
-  hipLaunchKernelGGL(gftt_sobel_kernel, grid, block, 0, c->stream, (const uint8_t*)c->image.p, width, height,
-                     (u32)width, (float2*)(d + o_grad), (size_t)0);
-  hipLaunchKernelGGL(gftt_mineig_kernel, grid, block, 0, c->stream, (const float2*)(d + o_grad), width, height,
-                     (float*)(d + o_eig), d_misc);
+  const dim3 tiles((u32)((width + GFTT_TILE_W - 1) / GFTT_TILE_W), (u32)((height + GFTT_TILE_H - 1) / GFTT_TILE_H));
+  hipLaunchKernelGGL(gftt_sobel_mineig_kernel, tiles, block, 0, c->stream, (const uint8_t*)c->image.p, width, height,
+                     (u32)width, (float*)(d + o_eig), d_misc, (size_t)0);
   hipLaunchKernelGGL(gftt_candidates_kernel, grid, block, 0, c->stream, (const float*)(d + o_eig), width, height,
                      (const u32*)d_misc, quality, (u64*)(d + o_cand), d_misc + 1, (u32)n);
   // order them on the device (the gradient area is free again); sized for the largest count the
@@ -1967,9 +1966,9 @@ int vsm_detect_and_describe_batch(vsm_ctx* c, const uint8_t* const* imgs, size_t
     u32* d_misc = (u32*)(d + o_misc);
     HIP_TRY(hipMemsetAsync(d_misc, 0, nb * 8, c->stream));
     const dim3 grid((u32)((width + 63) / 64), (u32)((height + 3) / 4), (u32)nb), block(256);
-    hipLaunchKernelGGL(gftt_sobel_kernel, grid, block, 0, c->stream, d_img, width, height, (u32)width, (float2*)(d + o_grad), n);
-    hipLaunchKernelGGL(gftt_mineig_kernel, grid, block, 0, c->stream, (const float2*)(d + o_grad), width, height,
-                       (float*)(d + o_eig), d_misc);
+    const dim3 tiles((u32)((width + GFTT_TILE_W - 1) / GFTT_TILE_W), (u32)((height + GFTT_TILE_H - 1) / GFTT_TILE_H), (u32)nb);
+    hipLaunchKernelGGL(gftt_sobel_mineig_kernel, tiles, block, 0, c->stream, d_img, width, height, (u32)width,
+                       (float*)(d + o_eig), d_misc, n);
     hipLaunchKernelGGL(gftt_candidates_kernel, grid, block, 0, c->stream, (const float*)(d + o_eig), width, height,
                        (const u32*)d_misc, 0.01, (u64*)(d + o_cand), d_misc + 1, (u32)n);
     const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + GFTT_RANK_BLOCK - 1) / GFTT_RANK_BLOCK);
