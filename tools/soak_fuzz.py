@@ -154,7 +154,13 @@ def front_end(budget, seed):
         if rng.random() < 0.3:
             os.environ["VSM_BATCH_CHUNK"] = str(int(rng.integers(1, 5)))
         try:
-            off, xy, ang, desc = m.detect_and_describe_batch(imgs, nf, rot)
+            if rng.random() < 0.3:  # the single-image entry point, image by image
+                parts = [m.detect_and_describe(im, nf, rot) for im in imgs]
+                off = np.zeros(n_img + 1, np.int64)
+                off[1:] = np.cumsum([len(p[0]) for p in parts])
+                xy, ang, desc = (np.concatenate([p[k] for p in parts]) for k in range(3))
+            else:
+                off, xy, ang, desc = m.detect_and_describe_batch(imgs, nf, rot)
         finally:
             os.environ.pop("VSM_BATCH_CHUNK", None)
 

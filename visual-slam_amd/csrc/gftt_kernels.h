@@ -189,13 +189,19 @@ __host__ __device__ __forceinline__ bool gftt_lds_sorts(u32 n, u32 cap) {
   return n <= GFTT_RANK_SORT_MAX && gftt_sort_size(n) <= cap;
 }
 // skip_lds_sorted: images gftt_lds_sort_kernel orders (a batch) are left alone.
+// host_count / host_first (single image; may be null): MAPPED host memory that receives the candidate
+// count and the first host_first_n ordered candidates straight from this kernel -- what the host's
+// sequential pass reads next, without a copy in between.
 __global__ __launch_bounds__(GFTT_RANK_BLOCK) void gftt_rank_sort_kernel(const u64* __restrict__ cand,
                                                                          const u32* __restrict__ count, u32 cap,
-                                                                         u64* __restrict__ sorted, u32 skip_lds_sorted) {
+                                                                         u64* __restrict__ sorted, u32 skip_lds_sorted,
+                                                                         u32* __restrict__ host_count,
+                                                                         u64* __restrict__ host_first, u32 host_first_n) {
   __shared__ u64 tile[256];
   count += 2 * blockIdx.z;
   cand += blockIdx.z * (size_t)cap;
   sorted += blockIdx.z * (size_t)cap;
+  if (host_count && blockIdx.x == 0 && threadIdx.x == 0) *host_count = *count;
   const u32 n = min(*count, cap);
   if (n > GFTT_RANK_SORT_MAX || blockIdx.x * GFTT_RANK_BLOCK >= n) return;  // block-uniform
   if (skip_lds_sorted && gftt_lds_sorts(n, cap)) return;
@@ -218,7 +224,11 @@ __global__ __launch_bounds__(GFTT_RANK_BLOCK) void gftt_rank_sort_kernel(const u
       r3 += tile[j + 3] > mine ? 1u : 0u;
     }
   }
-  if (i < n) sorted[(r0 + r1) + (r2 + r3)] = mine;
+  if (i < n) {
+    const u32 rank = (r0 + r1) + (r2 + r3);
+    sorted[rank] = mine;
+    if (host_first && rank < host_first_n) host_first[rank] = mine;
+  }
 }
 
 // A batch of images: the brute-force order above is n^2 work per image whatever the batch (15 k

@@ -1264,6 +1264,7 @@ static int stage_image(vsm_ctx* c, const uint8_t* img, int width, int height, si
   if (pitch == (size_t)width) memcpy(h, img, img_bytes);
   else
     for (int y = 0; y < height; y++) memcpy(h + (size_t)y * width, img + (size_t)y * pitch, (size_t)width);
+  // (a copy kernel reading mapped host memory, as vsm_match_pair uses for its 96 KB, gains nothing at 361 KB)
   HIP_TRY(hipMemcpyAsync(c->image.p, h, img_bytes, hipMemcpyHostToDevice, c->stream));
   return VSM_OK;
 }
@@ -1288,23 +1289,28 @@ static int check_corners(const double* corners_xy, size_t n, int width, int heig
 }
 
 // computeAngles + computeDescriptors on the image already staged in c->image (mutex held,
-// device current, corners validated).
+// device current, corners validated).  As in vsm_match_pair everything stays in the compute queue: the
+// kernels read the corners and (cos, sin) from, and write the moments and descriptors to, MAPPED host
+// memory (each value crosses the bus once; a copy kernel or SDMA copy per direction and stage cost
+// 5-10 us each with its waits).  Without a mapping the same buffers are copied.
 static int orb_on_device(vsm_ctx* c, int width, int height, const double* corners_xy, size_t n,
                          int rotate_features, const double* angles_in, double* angles_out, uint64_t* desc_out) {
-  // pinned staging: [corners | (cos, sin)] up, [moments | descriptors] down
+  // host staging: [corners | (cos, sin)] up, [moments | descriptors] down
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t o_xy = 0, o_cs = al(n * 16), up_bytes = o_cs + al(n * 16);
   const size_t o_mom = 0, o_desc = al(n * 8), down_bytes = o_desc + n * DESC_BYTES;
-  VSM_TRY(c->pin.reserve(up_bytes + down_bytes));
-  VSM_TRY(c->stage.reserve(up_bytes));
-  VSM_TRY(c->w_out.reserve(down_bytes));
-  char* h = (char*)c->pin.p;
-  char* hd = h + up_bytes;
-  memcpy(h + o_xy, corners_xy, n * 16);
-  char* d = (char*)c->stage.p;
-  char* dd = (char*)c->w_out.p;
+  VSM_TRY(c->pin_in.reserve(up_bytes));
+  VSM_TRY(c->pin_out.reserve(down_bytes));
+  const bool map_in = c->pin_in.dev != nullptr, map_out = c->pin_out.dev != nullptr;
+  if (!map_in) VSM_TRY(c->stage.reserve(up_bytes));
+  if (!map_out) VSM_TRY(c->w_out.reserve(down_bytes));
+  char* h = (char*)c->pin_in.p;
+  char* hd = (char*)c->pin_out.p;
+  const char* d = map_in ? (const char*)c->pin_in.dev : (const char*)c->stage.p;  // what the kernels read
+  char* dd = map_out ? (char*)c->pin_out.dev : (char*)c->w_out.p;                 // what they write
   const uint8_t* d_img = (const uint8_t*)c->image.p;
-  HIP_TRY(hipMemcpyAsync(d + o_xy, h + o_xy, n * 16, hipMemcpyHostToDevice, c->stream));
+  memcpy(h + o_xy, corners_xy, n * 16);
+  if (!map_in) HIP_TRY(hipMemcpyAsync(c->stage.p, h + o_xy, n * 16, hipMemcpyHostToDevice, c->stream));
   double* cs = (double*)(h + o_cs);
   std::vector<double> ang_local;
   double* ang = angles_out;
@@ -1318,7 +1324,7 @@ static int orb_on_device(vsm_ctx* c, int width, int height, const double* corner
     hipLaunchKernelGGL(orb_moments_kernel, dim3((u32)((n + 3) / 4)), dim3(256), 0, c->stream, d_img, width,
                        height, (u32)width, (const double2*)(d + o_xy), (u32)n, (int2*)(dd + o_mom), (const u32*)nullptr, (size_t)0);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(hd + o_mom, dd + o_mom, n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!map_out) HIP_TRY(hipMemcpyAsync(hd + o_mom, dd + o_mom, n * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int32_t* mom = (const int32_t*)(hd + o_mom);
     for (size_t i = 0; i < n; i++)  // keypoints.h:195, host libm
@@ -1334,12 +1340,12 @@ static int orb_on_device(vsm_ctx* c, int width, int height, const double* corner
     cs[2 * i] = std::cos(ang[i]);
     cs[2 * i + 1] = std::sin(ang[i]);
   }
-  HIP_TRY(hipMemcpyAsync(d + o_cs, h + o_cs, n * 16, hipMemcpyHostToDevice, c->stream));
+  if (!map_in) HIP_TRY(hipMemcpyAsync((char*)c->stage.p + o_cs, h + o_cs, n * 16, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(orb_descriptor_kernel, dim3((u32)n), dim3(256), 0, c->stream, d_img, width, height,
                      (u32)width, (const double2*)(d + o_xy), (const double2*)(d + o_cs), (u32)n,
                      (u64*)(dd + o_desc), (const u32*)nullptr, (size_t)0);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(hd + o_desc, dd + o_desc, n * DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
+  if (!map_out) HIP_TRY(hipMemcpyAsync(hd + o_desc, dd + o_desc, n * DESC_BYTES, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   memcpy(desc_out, hd + o_desc, n * DESC_BYTES);
   return VSM_OK;
@@ -1433,15 +1439,21 @@ static int gftt_on_device(vsm_ctx* c, int width, int height, int max_corners, do
   // order them on the device (the gradient area is free again); sized for the largest count the
   // kernel sorts -- it reads the real count itself, so no host round trip is needed in between
   const u32 sort_blocks = (u32)((std::min<size_t>(n, GFTT_RANK_SORT_MAX) + GFTT_RANK_BLOCK - 1) / GFTT_RANK_BLOCK);
-  hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks), dim3(GFTT_RANK_BLOCK), 0, c->stream, (const u64*)(d + o_cand),
-                     (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad), 0u);
-  HIP_TRY(hipGetLastError());
-  // one speculative download: the count and the first GFTT_FIRST_COPY ordered candidates
+  // The count and the first GFTT_FIRST_COPY ordered candidates come down speculatively: written by the
+  // sort kernel itself into mapped host memory (two copies and their waits cost ~15 us), else copied.
   constexpr size_t GFTT_FIRST_COPY = 4096;
-  VSM_TRY(c->pin.reserve(256 + std::max<size_t>(GFTT_FIRST_COPY, 1) * 8));
-  char* hp = (char*)c->pin.p;
-  HIP_TRY(hipMemcpyAsync(hp, d_misc, 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(hp + 256, d + o_grad, std::min(n, GFTT_FIRST_COPY) * 8, hipMemcpyDeviceToHost, c->stream));
+  VSM_TRY(c->pin_out.reserve(256 + GFTT_FIRST_COPY * 8));
+  const bool mapped = c->pin_out.dev != nullptr;
+  char* hp = (char*)c->pin_out.p;
+  char* hp_dev = (char*)c->pin_out.dev;
+  hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks), dim3(GFTT_RANK_BLOCK), 0, c->stream, (const u64*)(d + o_cand),
+                     (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad), 0u, mapped ? (u32*)hp_dev + 1 : (u32*)nullptr,
+                     mapped ? (u64*)(hp_dev + 256) : (u64*)nullptr, (u32)GFTT_FIRST_COPY);
+  HIP_TRY(hipGetLastError());
+  if (!mapped) {
+    HIP_TRY(hipMemcpyAsync(hp, d_misc, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hp + 256, d + o_grad, std::min(n, GFTT_FIRST_COPY) * 8, hipMemcpyDeviceToHost, c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   const size_t nc = std::min<size_t>(((const u32*)hp)[1], n);
   if (nc == 0) return VSM_OK;
@@ -1977,7 +1989,8 @@ int vsm_detect_and_describe_batch(vsm_ctx* c, const uint8_t* const* imgs, size_t
                        (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad));
     if (!gftt_lds_sorts((u32)std::min<size_t>(n, GFTT_RANK_SORT_MAX), (u32)n))  // small images: the padded size may not fit
       hipLaunchKernelGGL(gftt_rank_sort_kernel, dim3(sort_blocks, 1, (u32)nb), dim3(GFTT_RANK_BLOCK), 0, c->stream,
-                         (const u64*)(d + o_cand), (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad), 1u);
+                         (const u64*)(d + o_cand), (const u32*)(d_misc + 1), (u32)n, (u64*)(d + o_grad), 1u, (u32*)nullptr,
+                         (u64*)nullptr, 0u);
     HIP_TRY(hipGetLastError());
     // -- one download: the (max key, count) pairs and the first ordered candidates of every image
     const size_t h_cand = al(nb * 8);
