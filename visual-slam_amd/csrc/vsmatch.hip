@@ -1387,6 +1387,10 @@ struct MinDistancePass {
       gh = (height + cell - 1) / cell;
       head.assign((size_t)gw * gh, -1);
     }
+    const size_t expect = max_corners > 0 ? std::min<size_t>((size_t)max_corners, 8192) : 2048;
+    next.reserve(expect);
+    kept.reserve(expect);
+    xy.reserve(2 * expect);
   }
   void feed(const u64* cand, size_t nc) {
     for (size_t k = 0; k < nc && !done; k++) {
