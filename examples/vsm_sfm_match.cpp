@@ -1,0 +1,66 @@
+// vsm_sfm_match.cpp -- the matching steps of `sfm` on its cached files, on the GPU, without the GUI.
+//
+//   vsm_sfm_match <corners.cereal> <matches.cereal> [all|stereo] [threshold=70] [dist_2_best=1.2]
+//
+// Reads the corners.cereal that detect_keypoints() saved (src/sfm.cpp:1203-1211), matches
+//   all:    every pair of images of different frames -- the pair list of match_all(), sfm.cpp:1285-1290,
+//           (i, j) for j < i over the images in file order -- as ONE batch (the loop at 1295-1321);
+//   stereo: camera 0 against camera 1 of every frame (match_stereo(), sfm.cpp:1234-1255);
+// with visnav::matchDescriptors' semantics (keypoints.h:247-361; defaults = sfm.cpp:200-202) and writes
+// the matches.cereal that sfm saves (sfm.cpp:1262-1270, 1342-1350).  MatchData::matches is filled;
+// T_i_j and inliers stay empty (findInliersEssential / findInliersRansac are outside this library:
+// the next step of the reference reads the file and can run them).
+// Needs only include/ and libvsmatch.so -- no cereal, Eigen, TBB, Pangolin or OpenCV:
+//   g++ -std=c++14 -O2 -Iinclude examples/vsm_sfm_match.cpp -Lvisual-slam_amd -lvsmatch -pthread -o vsm_sfm_match
+// VSM_DEVICES=0,1,... spreads the batch over several GPUs (keypoints_gpu.h).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "visnav_amd/cereal_lite.h"
+#include "visnav_amd/keypoints_gpu.h"
+
+int main(int argc, char** argv) {
+  if (argc < 3 || argc > 6) {
+    std::fprintf(stderr, "usage: %s <corners.cereal> <matches.cereal> [all|stereo] [threshold=70] [dist_2_best=1.2]\n", argv[0]);
+    return 2;
+  }
+  namespace cl = visnav::cereal_lite;
+  const bool stereo = argc > 3 && std::strcmp(argv[3], "stereo") == 0;
+  if (argc > 3 && !stereo && std::strcmp(argv[3], "all") != 0) {
+    std::fprintf(stderr, "mode must be `all` or `stereo`\n");
+    return 2;
+  }
+  const int threshold = argc > 4 ? std::atoi(argv[4]) : 70;   // feature_match_max_dist, sfm.cpp:200
+  const double ratio = argc > 5 ? std::atof(argv[5]) : 1.2;   // feature_match_test_next_best, sfm.cpp:202
+  try {
+    const cl::Corners corners = cl::read_corners(argv[1]);
+    std::vector<const std::vector<std::bitset<256>>*> sets;
+    for (const auto& kv : corners) sets.push_back(&kv.second.corner_descriptors);
+    std::vector<std::pair<int, int>> ids_to_match;
+    for (size_t i = 0; i < corners.size(); i++)
+      for (size_t j = 0; j < (stereo ? corners.size() : i); j++) {
+        const cl::FrameCamId &a = corners[i].first, &b = corners[j].first;
+        if (stereo ? (a.frame_id == b.frame_id && a.cam_id == 0 && b.cam_id == 1)  // sfm.cpp:1235
+                   : (a.frame_id != b.frame_id))                                   // sfm.cpp:1288
+          ids_to_match.emplace_back(int(i), int(j));
+      }
+    std::vector<std::vector<std::pair<int, int>>> lists;
+    visnav::matchDescriptorsBatch(sets, ids_to_match, lists, threshold, ratio);
+    cl::Matches out;
+    size_t total = 0;
+    for (size_t k = 0; k < ids_to_match.size(); k++) {
+      cl::MatchData md;
+      md.matches = std::move(lists[k]);
+      total += md.matches.size();
+      out.push_back({{corners[ids_to_match[k].first].first, corners[ids_to_match[k].second].first}, std::move(md)});
+    }
+    cl::write_matches(argv[2], out);
+    std::printf("vsm_sfm_match: %zu images, %zu %s pairs, %zu matches -> %s\n", corners.size(), ids_to_match.size(),
+                stereo ? "stereo" : "non-stereo", total, argv[2]);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "vsm_sfm_match: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -153,6 +153,33 @@ def test_cereal_corners_file_in_matches_file_out(tmp_path):
         assert np.array_equal(stereo[f], o.match(desc[off[a]:off[a + 1]], desc[off[b]:off[b + 1]], 70, 1.2)) and len(stereo[f]) > 50
 
 
+def test_cpp_tool_corners_file_in_matches_file_out(tmp_path):
+    """The same round trip from C++ (examples/vsm_sfm_match.cpp: cereal_lite.h + matchDescriptorsBatch,
+    no cereal / Eigen / TBB): the binary built by build() reads the corners file, matches the pairs of
+    match_all (sfm.cpp:1285-1321) resp. match_stereo (sfm.cpp:1234-1255) and writes matches.cereal;
+    the Python reader gets every list back equal to the oracle's, keyed as the reference keys them."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(cases.GOLDEN.rstrip("/")), "..", "examples", "vsm_sfm_match")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    src = os.path.join(cases.GOLDEN, "ex4_corners.cereal")
+    fcids, desc, off = cio.corners_to_database(cio.load_corners_binary(src))
+    where = {fc: k for k, fc in enumerate(fcids)}
+    o = binding.port()
+    for mode, n_pairs, thr, ratio in (("all", 180, 70, 1.2), ("stereo", 10, 80, 1.1)):
+        path = str(tmp_path / (mode + ".cereal"))
+        r = subprocess.run([exe, src, path, mode, str(thr), str(ratio)], capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0 and "vsm_sfm_match:" in r.stdout, r.stdout + r.stderr
+        back = cio.load_matches_binary(path)
+        assert len(back) == n_pairs
+        for (a, b), md in back:
+            i, j = where[a], where[b]
+            assert (a[0] != b[0] and j < i) if mode == "all" else (a[0] == b[0] and a[1] == 0 and b[1] == 1)
+            assert np.array_equal(md["matches"], o.match(desc[off[i]:off[i + 1]], desc[off[j]:off[j + 1]], thr, ratio)), (mode, a, b)
+            assert len(md["inliers"]) == 0
+        assert len({k for k, _ in back}) == n_pairs
+    assert subprocess.run([exe, "/nonexistent", str(tmp_path / "x")], capture_output=True).returncode == 1
+
+
 def test_attach_again_after_rewriting_the_buffer():
     """vsm_db_attach reads the descriptors once (the group table of the consumer kernels): a caller
     that rewrites an attached buffer attaches again (include/vsmatch.h).  Two real-like databases
