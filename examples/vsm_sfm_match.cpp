@@ -1,11 +1,15 @@
 // vsm_sfm_match.cpp -- the matching steps of `sfm` on its cached files, on the GPU, without the GUI.
 //
 //   vsm_sfm_match <corners.cereal> <matches.cereal> [all|stereo] [threshold=70] [dist_2_best=1.2]
+//   vsm_sfm_match <corners.cereal> <matches.cereal> bow <ORBvoc.cereal> [num_bow_candidates=25] [threshold] [dist_2_best]
 //
 // Reads the corners.cereal that detect_keypoints() saved (src/sfm.cpp:1203-1211), matches
 //   all:    every pair of images of different frames -- the pair list of match_all(), sfm.cpp:1285-1290,
 //           (i, j) for j < i over the images in file order -- as ONE batch (the loop at 1295-1321);
 //   stereo: camera 0 against camera 1 of every frame (match_stereo(), sfm.cpp:1234-1255);
+//   bow:    the candidate pairs of match_bow(), sfm.cpp:1357-1423 -- every image's BoW vector through the
+//           vocabulary tree (bow_voc.h:94-131), every image against the num_bow_candidates (sfm.cpp:209)
+//           best of the images before it in the file (bow_db.h:63-131), pairs of one frame skipped;
 // with visnav::matchDescriptors' semantics (keypoints.h:247-361; defaults = sfm.cpp:200-202) and writes
 // the matches.cereal that sfm saves (sfm.cpp:1262-1270, 1342-1350).  MatchData::matches is filled;
 // T_i_j and inliers stay empty (findInliersEssential / findInliersRansac are outside this library:
@@ -17,28 +21,43 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "visnav_amd/bow_db_gpu.h"
+#include "visnav_amd/bow_voc_gpu.h"
 #include "visnav_amd/cereal_lite.h"
 #include "visnav_amd/keypoints_gpu.h"
 
 int main(int argc, char** argv) {
-  if (argc < 3 || argc > 6) {
-    std::fprintf(stderr, "usage: %s <corners.cereal> <matches.cereal> [all|stereo] [threshold=70] [dist_2_best=1.2]\n", argv[0]);
-    return 2;
-  }
   namespace cl = visnav::cereal_lite;
   const bool stereo = argc > 3 && std::strcmp(argv[3], "stereo") == 0;
-  if (argc > 3 && !stereo && std::strcmp(argv[3], "all") != 0) {
-    std::fprintf(stderr, "mode must be `all` or `stereo`\n");
+  const bool bow = argc > 3 && std::strcmp(argv[3], "bow") == 0;
+  const int first_opt = bow ? 6 : 4;  // where threshold and ratio sit
+  if (argc < 3 || argc > first_opt + 2 || (bow && argc < 5) ||
+      (argc > 3 && !stereo && !bow && std::strcmp(argv[3], "all") != 0)) {
+    std::fprintf(stderr,
+                 "usage: %s <corners.cereal> <matches.cereal> [all|stereo] [threshold=70] [dist_2_best=1.2]\n"
+                 "       %s <corners.cereal> <matches.cereal> bow <ORBvoc.cereal> [num_bow_candidates=25] [threshold] [dist_2_best]\n",
+                 argv[0], argv[0]);
     return 2;
   }
-  const int threshold = argc > 4 ? std::atoi(argv[4]) : 70;   // feature_match_max_dist, sfm.cpp:200
-  const double ratio = argc > 5 ? std::atof(argv[5]) : 1.2;   // feature_match_test_next_best, sfm.cpp:202
+  const size_t num_bow_candidates = bow && argc > 5 ? size_t(std::atol(argv[5])) : 25;     // sfm.cpp:209
+  const int threshold = argc > first_opt ? std::atoi(argv[first_opt]) : 70;               // feature_match_max_dist, sfm.cpp:200
+  const double ratio = argc > first_opt + 1 ? std::atof(argv[first_opt + 1]) : 1.2;       // feature_match_test_next_best, sfm.cpp:202
   try {
     const cl::Corners corners = cl::read_corners(argv[1]);
     std::vector<const std::vector<std::bitset<256>>*> sets;
     for (const auto& kv : corners) sets.push_back(&kv.second.corner_descriptors);
     std::vector<std::pair<int, int>> ids_to_match;
-    for (size_t i = 0; i < corners.size(); i++)
+    if (bow) {  // sfm.cpp:1373-1392 with the query-then-insert loop as one launch over the finished database
+      const visnav::BowVocabularyGpu voc(argv[4]);
+      visnav::BowDatabaseGpu<cl::FrameCamId> db;
+      for (const auto& kv : corners) {
+        visnav::BowDatabaseGpu<cl::FrameCamId>::BowVector v;
+        voc.transform(kv.second.corner_descriptors, v);
+        db.insert(kv.first, v);
+      }
+      db.selectPairs(num_bow_candidates, ids_to_match);
+    }
+    for (size_t i = 0; i < (bow ? 0 : corners.size()); i++)
       for (size_t j = 0; j < (stereo ? corners.size() : i); j++) {
         const cl::FrameCamId &a = corners[i].first, &b = corners[j].first;
         if (stereo ? (a.frame_id == b.frame_id && a.cam_id == 0 && b.cam_id == 1)  // sfm.cpp:1235
@@ -57,7 +76,7 @@ int main(int argc, char** argv) {
     }
     cl::write_matches(argv[2], out);
     std::printf("vsm_sfm_match: %zu images, %zu %s pairs, %zu matches -> %s\n", corners.size(), ids_to_match.size(),
-                stereo ? "stereo" : "non-stereo", total, argv[2]);
+                stereo ? "stereo" : bow ? "BoW candidate" : "non-stereo", total, argv[2]);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "vsm_sfm_match: %s\n", e.what());
     return 1;

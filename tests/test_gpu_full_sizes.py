@@ -178,6 +178,30 @@ def test_cpp_tool_corners_file_in_matches_file_out(tmp_path):
             assert len(md["inliers"]) == 0
         assert len({k for k, _ in back}) == n_pairs
     assert subprocess.run([exe, "/nonexistent", str(tmp_path / "x")], capture_output=True).returncode == 1
+    # match_bow (sfm.cpp:1357-1423) through a vocabulary file (synthetic: the reference's ORBvoc.cereal is not in
+    # its checkout): words by the oracle's descent, vectors, the oracle's BowDatabase loop, the oracle's matcher
+    synth = importlib.import_module("visual-slam_amd.synth")
+    voc = synth.vocabulary(8, 3, seed=5, zero_weight_frac=0.02)
+    leaves = np.flatnonzero(np.diff(voc["child_off"].astype(np.int64)) == 0)
+    rng = np.random.default_rng(8)  # descriptors near the leaves, so that the images share words
+    kd = [(fc, {"corners": np.zeros((60, 2)), "corner_angles": np.zeros(60),
+                "corner_descriptors": voc["node_desc"][leaves[rng.integers(0, len(leaves), 60)]]
+                ^ synth.flip_masks(60, 9, k, levels=(4, 5))}) for k, fc in enumerate(fcids[:12])]
+    cfile, vfile, mfile = (str(tmp_path / n) for n in ("c.cereal", "voc.cereal", "bow.cereal"))
+    cio.save_corners_binary(cfile, kd)
+    cio.save_vocabulary_binary(vfile, voc)
+    r = subprocess.run([exe, cfile, mfile, "bow", vfile, "4", "90", "1.1"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and "BoW candidate" in r.stdout, r.stdout + r.stderr
+    d2 = np.concatenate([k["corner_descriptors"] for _, k in kd])
+    off2 = (np.arange(13) * 60).astype(np.uint32)
+    words, weights = o.bow_words(d2, voc)
+    csr = vsm.matcher.bow_vectors_of_images(words, weights, off2)
+    want_pairs, want_score = binding.match_bow_pairs(fcids[:12], *csr, 4)
+    assert len(set(want_score.tolist())) == len(want_score) and len(want_pairs) > 10  # no equal scores: one right list
+    back = cio.load_matches_binary(mfile)
+    assert [(fcids.index(a), fcids.index(b)) for (a, b), _ in back] == [tuple(p) for p in want_pairs.tolist()]
+    for ((a, b), md), (i, j) in zip(back, want_pairs.tolist()):
+        assert np.array_equal(md["matches"], o.match(d2[off2[i]:off2[i + 1]], d2[off2[j]:off2[j + 1]], 90, 1.1))
 
 
 def test_attach_again_after_rewriting_the_buffer():
