@@ -64,3 +64,43 @@ def test_gpu_pipeline_reproduces_goldens():
         for k, p in enumerate(allp):
             got = lists[int(offs[k]): int(offs[k + 1])]
             assert len(got) == p["matches"] and sha(got) == p["sha256"], p
+
+
+@pytest.mark.gpu
+def test_cpp_tools_images_in_matches_file_out(tmp_path):
+    """The same pipeline from C++, file to file: examples/vsm_sfm_detect (the 8 frames as PGM files ->
+    corners.cereal, detect_keypoints() of sfm.cpp:1191-1214 in one batch call) and examples/vsm_sfm_match
+    (-> matches.cereal, match_stereo / match_all): the files hold the goldens -- the reference's own corner
+    lists and descriptors and its real matchDescriptors' lists."""
+    import subprocess
+    cio = importlib.import_module("visual-slam_amd.cereal_io")
+    ex = os.path.join(os.path.dirname(cases.GOLDEN), "..", "examples")
+    detect, match = os.path.join(ex, "vsm_sfm_detect"), os.path.join(ex, "vsm_sfm_match")
+    assert os.path.exists(detect) and os.path.exists(match), "run __graft_entry__.build() first"
+    lines = []
+    for k in range(len(G["images"])):
+        im = image(k)
+        p = tmp_path / f"{k}.pgm"
+        with open(p, "wb") as f:
+            f.write(b"P5\n# frame %d\n%d %d\n255\n" % (k, im.shape[1], im.shape[0]) + np.ascontiguousarray(im).tobytes())
+        lines.append(f"{k // 2} {k % 2} {p}")
+    (tmp_path / "images.txt").write_text("\n".join(lines) + "\n")
+    corners = str(tmp_path / "corners.cereal")
+    r = subprocess.run([detect, str(tmp_path / "images.txt"), corners, "1500", "1"], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0 and "vsm_sfm_detect: 8 images" in r.stdout, r.stdout + r.stderr
+    items = cio.load_corners_binary(corners)
+    assert [fc for fc, _ in items] == [(k // 2, k % 2) for k in range(8)]
+    for (fc, kd), rec in zip(items, G["images"]):
+        assert len(kd["corners"]) == rec["corners"] and sha(np.asarray(kd["corners"], np.float64)) == rec["corners_sha256"]
+        assert sha(np.asarray(kd["corner_descriptors"], np.uint64)) == rec["descriptors_sha256"]
+    for mode, kind in (("stereo", "stereo"), ("all", "all")):
+        out = str(tmp_path / (mode + ".cereal"))
+        r = subprocess.run([match, corners, out, mode], capture_output=True, text=True, timeout=100)
+        assert r.returncode == 0, r.stdout + r.stderr
+        back = {(a, b): md for (a, b), md in cio.load_matches_binary(out)}
+        want = [p for p in G["pairs"] if p["kind"] == kind]
+        assert len(back) == len(want)
+        for p in want:
+            md = back[((p["i"] // 2, p["i"] % 2), (p["j"] // 2, p["j"] % 2))]
+            got = np.asarray(md["matches"], np.int32).reshape(-1, 2)
+            assert len(got) == p["matches"] and sha(got) == p["sha256"], p
