@@ -8,8 +8,10 @@
 #         -mllvm -amdgpu-mfma-vgpr-form -I../../include -I../../visual-slam_amd/csrc ../../visual-slam_amd/csrc/vsmatch.hip -o libvsmatch.so
 #   for t in shim_test shim_landmarks_test shim_orb_test shim_bowdb_test; do /opt/rocm/lib/llvm/bin/clang++ -std=c++14 -O1 -g \
 #         -fsanitize=address -I../../include ../../tests/cpp/$t.cpp -L. -lvsmatch -pthread -Wl,-rpath,'$ORIGIN' -o $t; done
+#   for t in vsm_sfm_detect vsm_sfm_match; do /opt/rocm/lib/llvm/bin/clang++ -std=c++14 -O1 -g -fsanitize=address \
+#         -I../../include ../../examples/$t.cpp -L. -lvsmatch -pthread -Wl,-rpath,'$ORIGIN' -o $t; done
 # Results: round 1 all four runs clean; round 2 (with the BoW database shim and the multi-context batch) all six clean,
-# and again after the batch front end (host threads) was added.  In the last run (two contexts) ASan's own
+# and again after the batch front end (host threads) and the file-to-file tools of examples/ were added.  In the last run (two contexts) ASan's own
 # device allocator can fail a CHECK inside the HSA runtime's exit handler, after main has returned
 # (sanitizer_allocator_device.h:125 "dev_runtime_unloaded", under __cxa_finalize of libamdhip64): runtime
 # teardown order under the sanitizer, no frame of the library or the test in it.
@@ -40,6 +42,15 @@ want, _ = binding.match_bow_pairs([(i // 2, i % 2) for i in range(120)], *csr, 7
 for a, name in zip(csr, ("off", "words", "values")):
     a.tofile(f"{d}/bow/{name}.bin")
 want.astype(np.int32).tofile(d + "/bow/want.bin")
+# the file-to-file tools: four real frames as PGM files
+from tests.test_euroc_subset import image
+os.makedirs(d + "/sfm")
+with open(d + "/sfm/images.txt", "w") as lst:
+    for k in range(4):
+        im = image(k)
+        with open(f"{d}/sfm/{k}.pgm", "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (im.shape[1], im.shape[0]) + np.ascontiguousarray(im).tobytes())
+        lst.write(f"{k // 2} {k % 2} {d}/sfm/{k}.pgm\n")
 PY
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
 G=tests/golden
@@ -49,4 +60,9 @@ timeout -k 10 120 tools/asan_build/shim_orb_test $D/orb
 timeout -k 10 120 tools/asan_build/shim_orb_test $D/orb detect
 timeout -k 10 120 tools/asan_build/shim_bowdb_test $D/bow/off.bin $D/bow/words.bin $D/bow/values.bin $D/bow/want.bin 7 | tail -1
 VSM_DEVICES=0,0 timeout -k 10 120 tools/asan_build/shim_test $G/ex3_kd0.npy $G/ex3_kd1.npy $G/ex3_matches.npy | tail -1
+if [ -x tools/asan_build/vsm_sfm_detect ]; then
+  timeout -k 10 120 tools/asan_build/vsm_sfm_detect $D/sfm/images.txt $D/sfm/corners.cereal 1500 1 | tail -1
+  timeout -k 10 120 tools/asan_build/vsm_sfm_match $D/sfm/corners.cereal $D/sfm/stereo.cereal stereo | tail -1
+  timeout -k 10 120 tools/asan_build/vsm_sfm_match $D/sfm/corners.cereal $D/sfm/all.cereal all 80 1.1 | tail -1
+fi
 echo "asan: all shim tests clean"
