@@ -257,6 +257,8 @@ int vsm_detect_and_describe(vsm_ctx* ctx, const uint8_t* img, int width, int hei
  * keep_as_database != 0 (needs num_features > 0): the descriptors also stay on the device as the
  * context's database, laid out by out_offsets as after vsm_db_upload, ready for vsm_match_pairs --
  * images in, match lists out, descriptors never leave the GPU.
+ * Environment: VSM_HOST_THREADS (1..64, default 8); VSM_TRACE_BATCH (set: stage times to stderr);
+ * VSM_BATCH_CHUNK (images per chunk, a test hook: the default fills 8 GB of work areas).
  */
 int vsm_detect_and_describe_batch(vsm_ctx* ctx, const uint8_t* const* imgs, size_t n_img, int width,
                                   int height, size_t pitch, int num_features, int rotate_features,
