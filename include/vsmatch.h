@@ -253,7 +253,8 @@ int vsm_detect_and_describe(vsm_ctx* ctx, const uint8_t* img, int width, int hei
  * vsm_detect_and_describe image by image, bit for bit: out_offsets[n_img + 1] (always written),
  * image i's keypoints at [out_offsets[i], out_offsets[i+1]) of corners_out[cap][2], angles_out[cap],
  * desc_out[cap][4] (each may be NULL: not wanted).  VSM_ERR_CAPACITY if cap is too small for the
- * wanted arrays (out_offsets then still holds the counts; n_img * num_features always suffices).
+ * wanted arrays (out_offsets then still holds the counts, no database is kept; n_img * num_features
+ * always suffices).
  * keep_as_database != 0 (needs num_features > 0): the descriptors also stay on the device as the
  * context's database, laid out by out_offsets as after vsm_db_upload, ready for vsm_match_pairs --
  * images in, match lists out, descriptors never leave the GPU.
