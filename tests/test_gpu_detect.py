@@ -197,6 +197,13 @@ def test_batch_front_end_errors_and_capacity(m):
     assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 95, 50, 1, C.c_void_p(off.ctypes.data), None, None, None, 0,
                                            0) == vsm.matcher.VSM_ERR_INVALID      # pitch < width
     assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 50, 1, None, None, None, None, 0, 0) == vsm.matcher.VSM_ERR_INVALID
+    # too small with keep_as_database: no database is kept (and the one before is gone, as after a failed upload)
+    m.db_upload(np.zeros((4, 4), np.uint64), np.array([0, 2, 4], np.uint32))
+    rc = L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 50, 1, C.c_void_p(off.ctypes.data), C.c_void_p(xy.ctypes.data),
+                                         None, None, 4, 1)
+    assert rc == vsm.matcher.VSM_ERR_CAPACITY
+    with pytest.raises(vsm.VsmError):
+        m.match_pairs(np.array([[0, 1]], np.uint32))
     # counts only (no array wanted), and the empty batch
     assert L.vsm_detect_and_describe_batch(m._h, ptrs, 2, 96, 64, 96, 50, 1, C.c_void_p(off.ctypes.data), None, None, None, 0, 0) == 0
     assert list(np.diff(off)) == want
