@@ -50,11 +50,9 @@ int main(int argc, char** argv) {
     if (bow) {  // sfm.cpp:1373-1392 with the query-then-insert loop as one launch over the finished database
       const visnav::BowVocabularyGpu voc(argv[4]);
       visnav::BowDatabaseGpu<cl::FrameCamId> db;
-      for (const auto& kv : corners) {
-        visnav::BowDatabaseGpu<cl::FrameCamId>::BowVector v;
-        voc.transform(kv.second.corner_descriptors, v);
-        db.insert(kv.first, v);
-      }
+      std::vector<visnav::BowDatabaseGpu<cl::FrameCamId>::BowVector> vectors;
+      voc.transformAll(sets, vectors);  // one descent call for every image
+      for (size_t i = 0; i < corners.size(); i++) db.insert(corners[i].first, vectors[i]);
       db.selectPairs(num_bow_candidates, ids_to_match);
     }
     for (size_t i = 0; i < (bow ? 0 : corners.size()); i++)

@@ -3,6 +3,7 @@
 //
 //   visnav::BowVocabularyGpu voc(vocab_path);             // bow_voc.h:55, reads ORBvoc.cereal
 //   voc.transform(kd.corner_descriptors, bow_vector);     // bow_voc.h:94-131 (src/sfm.cpp:1379)
+//   voc.transformAll(sets, bow_vectors);                  // the same for every image of a set, one GPU call
 //
 // `transform` has the reference's argument list and result: (word id, value) pairs in order of
 // first appearance, zero-weight words skipped, L1-normalised.  The per-feature descent
@@ -78,9 +79,34 @@ class BowVocabularyGpu {
     std::vector<WordId> words;
     std::vector<WordValue> weights;
     transformFeaturesToWords(features, words, weights);
+    accumulate(words.data(), weights.data(), words.size(), v);
+  }
+
+  // transform() for every image of a set with ONE descent call (the loop of match_bow, sfm.cpp:1373-1379,
+  // walks the tree image by image): out[i] = the BoW vector of *sets[i].
+  template <class BowVectorT>
+  void transformAll(const std::vector<const std::vector<TDescriptor>*>& sets, std::vector<BowVectorT>& out) const {
+    out.assign(sets.size(), BowVectorT());
+    if (voc_.size() == 0) return;
+    std::vector<TDescriptor> all;
+    for (const auto* s : sets) all.insert(all.end(), s->begin(), s->end());
+    std::vector<WordId> words;
+    std::vector<WordValue> weights;
+    transformFeaturesToWords(all, words, weights);
+    size_t at = 0;
+    for (size_t i = 0; i < sets.size(); i++) {
+      accumulate(words.data() + at, weights.data() + at, sets[i]->size(), out[i]);
+      at += sets[i]->size();
+    }
+  }
+
+ private:
+  // bow_voc.h:107-130: words in order of first appearance, zero-weight words skipped, L1-normalised
+  template <class BowVectorT>
+  static void accumulate(const WordId* words, const WordValue* weights, size_t n, BowVectorT& v) {
     WordValue sum_weight = 0;
     std::unordered_map<WordId, size_t> slot;  // position of a word in v (the reference searches linearly)
-    for (size_t i = 0; i < words.size(); i++) {
+    for (size_t i = 0; i < n; i++) {
       if (weights[i] == 0) continue;  // bow_voc.h:114
       sum_weight += weights[i];
       auto it = slot.find(words[i]);
@@ -94,7 +120,6 @@ class BowVocabularyGpu {
     for (auto& p : v) p.second /= sum_weight;
   }
 
- private:
   cereal_lite::Vocabulary voc_;
   uint64_t id_;
 };

@@ -57,6 +57,16 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "FAIL: first vocabulary after the second one used the same context\n");
       return 1;
     }
+    // transformAll: three sets (the features, none, their first half) with one descent call
+    std::vector<std::bitset<256>> none, half(features.begin(), features.begin() + features.size() / 2);
+    std::vector<std::pair<unsigned int, double>> bh;
+    voc.transform(half, bh);
+    std::vector<std::vector<std::pair<unsigned int, double>>> all;
+    voc.transformAll({&features, &none, &half}, all);
+    if (all.size() != 3 || all[0] != bow || !all[1].empty() || all[2] != bh) {
+      std::fprintf(stderr, "FAIL: transformAll\n");
+      return 1;
+    }
     std::printf("bow shim ok: %zu nodes, %zu features -> %zu words; two vocabularies on one thread\n", voc.size(),
                 features.size(), bow.size());
   } catch (const std::exception& e) {
