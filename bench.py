@@ -46,9 +46,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Roofline.  The scan computes a 256-bit Hamming distance as a dot product of +-1
+# Roofline.  The scan computes a 256-bit Hamming distance as a dot product of +-0.5
 # FP4 codes on the matrix cores (csrc/mfma_scan.h): 256 multiply-adds = 512 FLOP per comparison,
-# v_mfma_scale_f32_32x32x64_f8f6f4 with FP4 operands = 2 * 32*32*64 FLOP in 32 cycles per SIMD, so
+# v_mfma_f32_32x32x64_f8f6f4 with FP4 operands = 2 * 32*32*64 FLOP in 32 cycles per SIMD, so
 # peak = 1024 SIMDs x 4096 FLOP/clk x 2.4 GHz = 10.07 PFLOP/s (the dense FP4 figure of
 # MI355X_MICROARCH.md) = 19.66 T comparisons/s.
 # The popcount scan (v_xor_b32 + v_bcnt_u32_b32, the formulation of BASELINE.json's north_star,
@@ -364,7 +364,7 @@ def main():
     fwd_laneops = fwd["comparisons"] * LANE_OPS_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
     roofline = {
         "bound": "mfma", "kernel": "mfma_scan_kernel<8,1> (forward scans, the dominant kernel: FP4 +-1 dot products on "
-                                   "v_mfma_scale_f32_32x32x64_f8f6f4, one-wave workgroups, 256-query tiles)",
+                                   "v_mfma_f32_32x32x64_f8f6f4, one-wave workgroups, 256-query tiles)",
         "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
         "x_popcount_valu_roofline_measured_issue_rate": fwd_laneops / PEAK_TLANEOPS,
         "x_popcount_valu_roofline_nominal_64_lanes_per_clk": fwd_laneops / NOMINAL_TLANEOPS,

@@ -5,28 +5,33 @@
 //
 // The Hamming distance of two bit strings is a dot product: with a -> +1/-1 per bit,
 //     sum_k a_k * b_k = (#equal bits) - (#different bits) = 256 - 2 d.
-// v_mfma_scale_f32_32x32x64_f8f6f4 on FP4 (e2m1) operands multiplies a 32 x 64 tile by a 64 x 32
+// v_mfma_f32_32x32x64_f8f6f4 on FP4 (e2m1) operands multiplies a 32 x 64 tile by a 64 x 32
 // tile in 32 cycles per SIMD, so four of them give the 1024 distances of 32 train x 32 query
 // descriptors in 128 cycles; the popcount path (v_xor + v_bcnt, vsmatch_kernels.h) needs
-// 16 x 55.4 = 887 cycles for the same 1024 comparisons.  Every product is +1 or -1 and every sum
-// an integer of magnitude <= 256, all exact in the f32 accumulator: the distances are the
+// 16 x 55.4 = 887 cycles for the same 1024 comparisons.  Every product is +1/4 or -1/4 and every sum
+// a multiple of 1/4 of magnitude <= 64, all exact in the f32 accumulator: the distances are the
 // reference's, bit for bit.
 //
 // Operands.  Bits become FP4 codes:
-//     code = 0x2 | (bit << 3)        (0x2 = +1.0, 0xA = -1.0 in e2m1)
-//     reg s = ((w << s) & 0x88888888) | 0x22222222,  s = 0..3
+//     code = 0x1 | (bit << 3)        (0x1 = +0.5, 0x9 = -0.5 in e2m1)
+//     reg s = ((w << s) & 0x88888888) | 0x11111111,  s = 0..3
 // i.e. register s takes bits 3-s, 7-s, ... 31-s of the 32-bit word w.  That is a permutation of
 // the 32 k-positions, and a dot product does not care as long as both operands use the same
 // one.  Queries are expanded once per tile (from ~w, so that a product is +1 where the bits
-// DIFFER), train descriptors once per 32 x (32 NB) block of comparisons.  The block-scaled form
-// of the instruction multiplies every product by 2^-7.
+// DIFFER), train descriptors once per 32 x (32 NB) block of comparisons.  The instruction is the one
+// WITHOUT block scales (the builtin with both scale operands 0 selects it).  Rounds 1-2 used the
+// block-scaled form, codes +-1.0 scaled by 2^-7 into the binade [4, 8): that form is two instructions
+// to the hardware (v_mfma_ld_scale_b32 + the MFMA) and costs ~37 cycles of the pipe instead of 32 --
+// back to back on random codes 14.5 T comparisons/s against 17.4 T without scales (tools/mfma_rate.hip);
+// the scan went from 14.1-14.3 to 14.3-14.6 T (+2 %, same box: what bounds it now is the power the
+// VALU work beside the MFMAs takes -- 1.92 GHz against 2.12 GHz of the bare instruction).
 //
 // Results and tracking ("group form").
-//  * The accumulators start from sixteen REGISTERS, element i at 6.0 + i ulp:
-//    D'[i] = 6 + (2 d - 256) / 128 + i * 2^-21 = 4 + d / 64 + i * 2^-21.  All of [4, 8) is one
-//    binade, so the bit pattern of a result is 0x40800000 | d << 15 | i: the distance in bits
+//  * The accumulators start from sixteen REGISTERS, element i at 192.0 + i ulp:
+//    D'[i] = 192 + (2 d - 256) / 4 + i * 2^-16 = 128 + d / 2 + i * 2^-16.  All of [128, 256) is one
+//    binade, so the bit pattern of a result is 0x43000000 | d << 15 | i: the distance in bits
 //    15-22, the element number -- which orders like the train row, (i & 3) + 8 (i >> 2) + 4 h --
-//    in bits 0-3; every partial sum is a multiple of 2^-21 below 8, exact in f32.  Eight
+//    in bits 0-3; every partial sum is a multiple of 2^-16 in [128, 256], exact in f32.  Eight
 //    v_min3_i32 over the sixteen results of a lane give (distance, lowest row) at once.
 //  * A lane of the 32 x 32 result holds 16 train rows of ONE query: a GROUP.  Per step the lane
 //    keeps the two smallest group minima: second = med3(best, m, second), best = min(best,
@@ -44,7 +49,7 @@
 //  * The start value of (best, second) is distance `d_lim`: the matcher passes the smallest
 //    distance that can no longer change the accept test (keypoints.h:295-296; accept_limit in
 //    vsmatch.hip), the raw 2-NN entry point passes 256.  Distance 256 is never recorded
-//    (keypoints.h:259-262): its D' is 8.0, not below any start value.
+//    (keypoints.h:259-262): its D' is 256.0, not below any start value.
 //
 // History (round 1, tools/history/mfma_scan_forms.h, timed against this form by tools/mfma_scan.hip):
 // float keys d * 32768 + j behind a wave-level skip test (fast only while no lane of the wave
@@ -72,7 +77,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // 32-bit word -> four registers of FP4 codes.  The two masks come in REGISTERS (0x88888888 in an
-// SGPR, 0x22222222 in a VGPR): gfx950's three-operand encoding takes no literal, so with literal
+// SGPR, 0x11111111 in a VGPR): gfx950's three-operand encoding takes no literal, so with literal
 // masks the compiler emits v_and + v_or per register (44 instructions per 32 train rows with the
 // shifts); from registers it is one v_and_or_b32 (28).
 __device__ __forceinline__ i32x8 expand_bits_r(u32 w, u32 m88, u32 c22) {
@@ -83,10 +88,10 @@ __device__ __forceinline__ i32x8 expand_bits_r(u32 w, u32 m88, u32 c22) {
 }
 
 // cbsz = blgp = 4: FP4 e2m1 operands (FP8 e4m3 runs at half the rate with twice the registers:
-// 5.9 against 9.6 T with the first version of this kernel).  Block scales (e8m0): A x 2^0, B x 2^-7,
-// so that a product is +-1/128.
+// 5.9 against 9.6 T with the first version of this kernel).  Scale operands 0 / 0: the compiler emits
+// v_mfma_f32_32x32x64_f8f6f4, no block scales, so a product is +-1/4.
 __device__ __forceinline__ f32x16 mfma_step(const i32x8 a, const i32x8 b, const f32x16 c) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x78787878);
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0);
 }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
@@ -109,8 +114,9 @@ __device__ __forceinline__ void store_accept_mask(const AcceptMask& acc, const J
   if (lane == 0) acc.mask[(job.out_off >> 6) + (q_first >> 5)] = (u32)m;  // valid only in lanes 0..31
 }
 
-constexpr int GROUP_D_BASE = 0x40800000;  // bits of 4.0 = D' of distance 0
-constexpr int GROUP_D_256 = 0x41000000;   // bits of 8.0 = D' of distance 256
+constexpr int GROUP_D_BASE = 0x43000000;  // bits of 128.0 = D' of distance 0
+constexpr int GROUP_D_256 = 0x43800000;   // bits of 256.0 = D' of distance 256
+constexpr int GROUP_D_START = 0x43400000; // bits of 192.0 = the accumulators' start value (+ i ulp)
 // One tile = 32 * NB queries of a job (lane l: column l & 31 of each block of 32, half l >> 5 of
 // the k range) against the split's share of the train range, 32 rows at a time.  Software
 // pipeline over (32 train rows, query block) steps: the four MFMAs of the next step are issued
@@ -133,7 +139,7 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
   Job job = jobs[j0];
   const u32 c = lane & 31, h = lane >> 5;
 
-  u32 m88 = 0x88888888u, c22 = 0x22222222u;
+  u32 m88 = 0x88888888u, c22 = 0x11111111u;  // (the name is history: codes 0x1 / 0x9 = +-0.5)
   asm volatile("" : "+s"(m88), "+v"(c22));
   i32x8 B[NB][4];
 #pragma unroll
@@ -162,10 +168,10 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
     const u32 last_off = (t1 - 1) * 32u + h * 16u;
     auto row = [&](u32 off) { return *(const u32x4*)(tr + min(off, last_off)); };
     u32 off = (t0 + c) * 32u + h * 16u;  // this lane's row of the current step
-    // start values of the accumulators: 6.0 + i ulp, kept in registers for the whole scan
+    // start values of the accumulators: 192.0 + i ulp, kept in registers for the whole scan
     f32x16 zero;
 #pragma unroll
-    for (int i = 0; i < 16; i++) zero[i] = __int_as_float(0x40C00000 + i);
+    for (int i = 0; i < 16; i++) zero[i] = __int_as_float(GROUP_D_START + i);
     asm volatile("" : "+v"(zero));
     u32x4 w = row(off);
     u32x4 wn = row(off + 1024u);  // the step after: in flight while the current one is expanded
