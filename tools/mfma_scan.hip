@@ -50,6 +50,132 @@ __global__ void refine_all(const u32x4* db, const Job* jobs, uint2* scr) {
   }
 }
 
+#ifdef VSM_PRODUCT
+// EXPERIMENT (round 2, last hours; not in the library): the eight 256-query tiles of a job in ONE workgroup of
+// eight waves, the train operands of a step expanded by one wave and shared through LDS -- the other seven
+// waves read them with four ds_read_b128 instead of 28 VALU instructions.  Train sizes that are multiples of
+// 256 rows and query sets of up to 2048 only (no partial step, no remainder tiles): a measurement of what the
+// sharing is worth, against the shipped kernel on the same jobs.  Double-buffered: one barrier per 8 steps.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_shared_kernel(
+    const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs,
+    uint2* __restrict__ scratch, u32 d_lim) {
+  extern __shared__ u32x4 shared_a[];  // [2 buffers][8 steps][4 k-quarters][64 lanes]
+  constexpr int NB = 8;
+  const Job job = jobs[blockIdx.x];
+  const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const u32 c = lane & 31, h = lane >> 5, q0 = wave * 256;
+  if (q0 >= job.nq) {  // fewer than eight tiles: the wave still expands its steps and keeps the barriers
+  }
+  u32 m88 = 0x88888888u, c11 = 0x11111111u;
+  asm volatile("" : "+s"(m88), "+v"(c11));
+  i32x8 B[NB][4];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const u32 qi = min(q0 + b * 32 + c, job.nq - 1);
+    const u32x4 w = qbase[2 * (size_t)(job.q_off + qi) + h];
+    B[b][0] = expand_bits_r(~w.x, m88, c11);
+    B[b][1] = expand_bits_r(~w.y, m88, c11);
+    B[b][2] = expand_bits_r(~w.z, m88, c11);
+    B[b][3] = expand_bits_r(~w.w, m88, c11);
+  }
+  const int init = d_lim >= 256u ? GROUP_D_256 : GROUP_D_BASE | (int)(d_lim << 15);
+  int best[NB], second[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) best[b] = second[b] = init;
+  f32x16 zero;
+#pragma unroll
+  for (int i = 0; i < 16; i++) zero[i] = __int_as_float(GROUP_D_START + i);
+  asm volatile("" : "+v"(zero));
+  auto med3 = [](int p, int q, int r) {
+    return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
+  };
+  auto group_min = [](const int (&x)[16]) {
+    const int m0 = min3i(x[0], x[1], x[2]), m1 = min3i(x[3], x[4], x[5]), m2 = min3i(x[6], x[7], x[8]);
+    const int m3 = min3i(x[9], x[10], x[11]), m4 = min3i(x[12], x[13], x[14]);
+    return min(min3i(m0, m1, m2), min3i(m3, m4, x[15]));
+  };
+  const char* tr = (const char*)(tbase + 2 * (size_t)job.t_off);
+  const u32 super_steps = job.nt / 256;
+  u32 buf = 0;
+  auto my_rows = [&](u32 ss) { return *(const u32x4*)(tr + ((ss * 8 + wave) * 32 + c) * 32u + h * 16u); };
+  u32x4 w = super_steps ? my_rows(0) : u32x4{0, 0, 0, 0};
+  for (u32 ss = 0; ss < super_steps; ss++, buf ^= 1) {
+    {  // this wave's step of the eight: expand, share; the rows of the next eight go in flight
+      const i32x8 e0 = expand_bits_r(w.x, m88, c11), e1 = expand_bits_r(w.y, m88, c11);
+      const i32x8 e2 = expand_bits_r(w.z, m88, c11), e3 = expand_bits_r(w.w, m88, c11);
+      u32x4* dst = shared_a + ((buf * 8 + wave) * 4) * 64 + lane;
+      dst[0] = u32x4{(u32)e0[0], (u32)e0[1], (u32)e0[2], (u32)e0[3]};
+      dst[64] = u32x4{(u32)e1[0], (u32)e1[1], (u32)e1[2], (u32)e1[3]};
+      dst[128] = u32x4{(u32)e2[0], (u32)e2[1], (u32)e2[2], (u32)e2[3]};
+      dst[192] = u32x4{(u32)e3[0], (u32)e3[1], (u32)e3[2], (u32)e3[3]};
+      if (ss + 1 < super_steps) w = my_rows(ss + 1);
+    }
+    __syncthreads();
+    auto shared_step = [&](u32 st, i32x8 (&A)[4]) {
+      const u32x4* src = shared_a + ((buf * 8 + st) * 4) * 64 + lane;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const u32x4 v = src[m * 64];
+        A[m] = i32x8{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+      }
+    };
+    i32x8 A[4], An[4];
+    shared_step(0, A);
+    f32x16 D = zero;
+#pragma unroll
+    for (int m = 0; m < 4; m++) D = mfma_step(A[m], B[0][m], D);
+    for (u32 st = 0; st < 8; st++) {
+      const u32 step16 = (ss * 8 + st) * 16;
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        f32x16 Dn = zero;
+        if (b + 1 < NB) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) Dn = mfma_step(A[m], B[b + 1][m], Dn);
+        } else if (st + 1 < 8) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) Dn = mfma_step(An[m], B[0][m], Dn);
+        }
+        if (b == NB - 2 && st + 1 < 8) shared_step(st + 1, An);
+        asm volatile("" : "+v"(Dn));
+        int x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = __float_as_int(D[i]);
+        const int m = group_min(x);
+        second[b] = med3(best[b], m, second[b]);
+        best[b] = min(best[b], m | (int)step16);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        D = Dn;
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++) A[m] = An[m];
+    }
+  }
+  if (q0 >= job.nq) return;
+  uint2* out = scratch + job.out_off;
+  const u32 sentinel = d_lim >= 256u ? KEY_INIT : (d_lim << IDX_BITS);
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const u32 bb = (u32)best[b], sb = (u32)second[b];
+    const u32 i = bb & 15u;
+    const u32 row = 2 * ((bb >> 4) & 1023u) * 16 + 4 * h + (i & 3u) + 8 * (i >> 2);
+    const u32 kl = (int)bb < init ? ((((bb >> 15) & 255u) << IDX_BITS) | row) : sentinel;
+    const u32 sl = (int)(sb & ~32767u) < init ? (((sb >> 15) & 255u) << IDX_BITS) : sentinel;
+    const u32 ko = (u32)__shfl_xor((int)kl, 32), so = (u32)__shfl_xor((int)sl, 32);
+    const u32 kb = min(kl, ko), ks = min(min(sl, so), max(kl, ko));
+    const u32 qi = q0 + b * 32 + c;
+    if (h == 0 && qi < job.nq) out[qi] = make_uint2(kb, ks);
+  }
+}
+#endif
+
 // data of a little-endian .npy file of uint64 (version 1 header)
 static std::vector<unsigned long long> load_npy_u64(const char* path) {
   FILE* f = fopen(path, "rb");
@@ -135,7 +261,8 @@ int main(int argc, char** argv) {
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
   const V vs[] = {{"shipped NB8", 24, 8}, {"shipped NB4", 24, 4}, {"shipped NB2", 24, 2},
-                  {"NB8, 4-wave workgroups", 44, 8}, {"NB4, 4-wave workgroups", 44, 4}};
+                  {"NB8, 4-wave workgroups", 44, 8}, {"NB4, 4-wave workgroups", 44, 4},
+                  {"EXPERIMENT: train operands shared through LDS", 54, 8}};
 #else
   const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2},
                   {"mfma group NB8", 24, 8}, {"mfma group NB4", 24, 4}, {"mfma group NB2", 24, 2}};
@@ -149,6 +276,11 @@ int main(int argc, char** argv) {
       const dim3 g(groups * 8 * tiles), blk(64);
 #define ARGS (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, tiles, d_lim
 #ifdef VSM_PRODUCT
+      if (v.fmt == 54) {
+        if (N % 256 || N > 2048) { printf("(the LDS experiment needs N = a multiple of 256, at most 2048)\n"); break; }
+        CK(hipFuncSetAttribute((const void*)mfma_scan_shared_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        mfma_scan_shared_kernel<<<dim3(n_jobs), dim3(512), 65536>>>((const u32x4*)db, (const u32x4*)db, d_jobs, scr, d_lim);
+      } else
       if (v.fmt == 44) {  // tiles of a job in one workgroup (one CU: they share its L1), job-minor order
         const dim3 g4(n_jobs * ((tiles + 3) / 4)), b4(256);
 #define ARGS4 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, 0u, d_lim
@@ -174,7 +306,7 @@ int main(int argc, char** argv) {
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
     }
-    if (v.fmt == 24 || v.fmt == 44) {
+    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54) {
       CK(hipEventRecord(e0));
       refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr);
       CK(hipEventRecord(e1));
