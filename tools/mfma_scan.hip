@@ -58,13 +58,14 @@ __global__ void refine_all(const u32x4* db, const Job* jobs, uint2* scr) {
 // sharing is worth, against the shipped kernel on the same jobs.  Double-buffered: one barrier per 8 steps.
 // WAVES = 8: one workgroup per job and CU; WAVES = 4: two workgroups per job (1024 queries each) and per CU, each
 // wave expands one step of four -- a workgroup waiting at its barrier leaves the matrix cores to the other one.
-template <int WAVES>
+// SPW: steps a wave expands per barrier (a barrier per WAVES * SPW steps).
+template <int WAVES, int SPW = 1>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_shared_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs,
     uint2* __restrict__ scratch, u32 d_lim) {
   extern __shared__ u32x4 shared_a[];  // [2 buffers][WAVES steps][4 k-quarters][64 lanes]
   constexpr int NB = 8;
-  constexpr u32 PARTS = 8 / WAVES;
+  constexpr u32 PARTS = 8 / WAVES, S = WAVES * SPW;
   const Job job = jobs[blockIdx.x / PARTS];
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const u32 c = lane & 31, h = lane >> 5, q0 = ((blockIdx.x % PARTS) * WAVES + wave) * 256;
@@ -99,24 +100,28 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
     return min(min3i(m0, m1, m2), min3i(m3, m4, x[15]));
   };
   const char* tr = (const char*)(tbase + 2 * (size_t)job.t_off);
-  const u32 super_steps = job.nt / (32 * WAVES);
+  const u32 super_steps = job.nt / (32 * S);
   u32 buf = 0;
-  auto my_rows = [&](u32 ss) { return *(const u32x4*)(tr + ((ss * WAVES + wave) * 32 + c) * 32u + h * 16u); };
-  u32x4 w = super_steps ? my_rows(0) : u32x4{0, 0, 0, 0};
+  auto my_rows = [&](u32 ss, u32 k) { return *(const u32x4*)(tr + ((ss * S + wave * SPW + k) * 32 + c) * 32u + h * 16u); };
+  u32x4 wk[SPW];
+#pragma unroll
+  for (int k = 0; k < SPW; k++) wk[k] = super_steps ? my_rows(0, k) : u32x4{0, 0, 0, 0};
   for (u32 ss = 0; ss < super_steps; ss++, buf ^= 1) {
-    {  // this wave's step of the eight: expand, share; the rows of the next eight go in flight
+#pragma unroll
+    for (int k = 0; k < SPW; k++) {  // this wave's steps of the super-step: expand, share; the next ones go in flight
+      const u32x4 w = wk[k];
       const i32x8 e0 = expand_bits_r(w.x, m88, c11), e1 = expand_bits_r(w.y, m88, c11);
       const i32x8 e2 = expand_bits_r(w.z, m88, c11), e3 = expand_bits_r(w.w, m88, c11);
-      u32x4* dst = shared_a + ((buf * WAVES + wave) * 4) * 64 + lane;
+      u32x4* dst = shared_a + ((buf * S + wave * SPW + k) * 4) * 64 + lane;
       dst[0] = u32x4{(u32)e0[0], (u32)e0[1], (u32)e0[2], (u32)e0[3]};
       dst[64] = u32x4{(u32)e1[0], (u32)e1[1], (u32)e1[2], (u32)e1[3]};
       dst[128] = u32x4{(u32)e2[0], (u32)e2[1], (u32)e2[2], (u32)e2[3]};
       dst[192] = u32x4{(u32)e3[0], (u32)e3[1], (u32)e3[2], (u32)e3[3]};
-      if (ss + 1 < super_steps) w = my_rows(ss + 1);
+      if (ss + 1 < super_steps) wk[k] = my_rows(ss + 1, k);
     }
     __syncthreads();
     auto shared_step = [&](u32 st, i32x8 (&A)[4]) {
-      const u32x4* src = shared_a + ((buf * WAVES + st) * 4) * 64 + lane;
+      const u32x4* src = shared_a + ((buf * S + st) * 4) * 64 + lane;
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const u32x4 v = src[m * 64];
@@ -128,19 +133,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
     f32x16 D = zero;
 #pragma unroll
     for (int m = 0; m < 4; m++) D = mfma_step(A[m], B[0][m], D);
-    for (u32 st = 0; st < WAVES; st++) {
-      const u32 step16 = (ss * WAVES + st) * 16;
+    for (u32 st = 0; st < S; st++) {
+      const u32 step16 = (ss * S + st) * 16;
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         f32x16 Dn = zero;
         if (b + 1 < NB) {
 #pragma unroll
           for (int m = 0; m < 4; m++) Dn = mfma_step(A[m], B[b + 1][m], Dn);
-        } else if (st + 1 < WAVES) {
+        } else if (st + 1 < S) {
 #pragma unroll
           for (int m = 0; m < 4; m++) Dn = mfma_step(An[m], B[0][m], Dn);
         }
-        if (b == NB - 2 && st + 1 < WAVES) shared_step(st + 1, An);
+        if (b == NB - 2 && st + 1 < S) shared_step(st + 1, An);
         asm volatile("" : "+v"(Dn));
         int x[16];
 #pragma unroll
@@ -266,7 +271,8 @@ int main(int argc, char** argv) {
 #ifdef VSM_PRODUCT
   const V vs[] = {{"shipped NB8", 24, 8}, {"shipped NB4", 24, 4}, {"shipped NB2", 24, 2},
                   {"NB8, 4-wave workgroups", 44, 8}, {"NB4, 4-wave workgroups", 44, 4},
-                  {"EXPERIMENT: LDS-shared operands, 8 waves", 54, 8}, {"EXPERIMENT: LDS-shared operands, 4 waves", 54, 4}};
+                  {"EXPERIMENT: LDS-shared operands, 8 waves", 54, 8}, {"EXPERIMENT: LDS-shared operands, 4 waves", 54, 4},
+                  {"EXPERIMENT: LDS-shared, 4 waves x 2 steps", 54, 2}, {"shipped NB8 again", 24, 8}};
 #else
   const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2},
                   {"mfma group NB8", 24, 8}, {"mfma group NB4", 24, 4}, {"mfma group NB2", 24, 2}};
@@ -284,7 +290,11 @@ int main(int argc, char** argv) {
         if (N % 256 || N > 2048) { printf("(the LDS experiment needs N = a multiple of 256, at most 2048)\n"); break; }
         CK(hipFuncSetAttribute((const void*)mfma_scan_shared_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         if (v.nb == 8) mfma_scan_shared_kernel<8><<<dim3(n_jobs), dim3(512), 65536>>>((const u32x4*)db, (const u32x4*)db, d_jobs, scr, d_lim);
-        else mfma_scan_shared_kernel<4><<<dim3(n_jobs * 2), dim3(256), 32768>>>((const u32x4*)db, (const u32x4*)db, d_jobs, scr, d_lim);
+        else if (v.nb == 4) mfma_scan_shared_kernel<4><<<dim3(n_jobs * 2), dim3(256), 32768>>>((const u32x4*)db, (const u32x4*)db, d_jobs, scr, d_lim);
+        else {
+          CK(hipFuncSetAttribute((const void*)mfma_scan_shared_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+          mfma_scan_shared_kernel<4, 2><<<dim3(n_jobs * 2), dim3(256), 65536>>>((const u32x4*)db, (const u32x4*)db, d_jobs, scr, d_lim);
+        }
       } else
       if (v.fmt == 44) {  // tiles of a job in one workgroup (one CU: they share its L1), job-minor order
         const dim3 g4(n_jobs * ((tiles + 3) / 4)), b4(256);
