@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the descriptor-matching hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--strong]
+  python bench.py --gpus N --steps K --warmup W [--strong] [--workload nn2]
   N > 1: one rank per GPU over RCCL.  Either launched by torch.distributed.run (the driver does
   that) or directly -- then this process starts torch.distributed.run itself as a child, before
   anything here has touched a GPU, and exits with its code.
@@ -20,6 +20,16 @@ device-resident match lists.
       sizes) dealt block-cyclically over the ranks (blocks of 4096 consecutive pairs), every
       rank matching its share in one call, plus the gather of all lists to rank 0, device to
       device -- the reference's match_all (src/sfm.cpp:1276-1321) end to end.
+
+  N > 1, default mode: after the weak-scaling steps ONE whole-list step is run as well (sharded + gathered)
+      and reported as `strong_scaling` in the same line, so that the driver's flag-less `--gpus N` run also
+      answers north_star's strong-scaling target ("at least 7x at 8 GPUs"); and rank 0 checks a bounded
+      sample of the GATHERED lists against the CPU reference (`cpu_baseline`, `gpu_lists_bit_exact`): a
+      mismatch fails the run.
+  --workload nn2: BASELINE.json config 4 (1M x 1M, one direction, keypoints.h:256-290): the train set is
+      replicated by one broadcast, the queries are sharded in contiguous blocks, every rank runs
+      vsm_nn2_device on its block, one all-gather on the devices returns the three int32 result arrays
+      everywhere; a step = the whole job (strong scaling).
 
 value = 256-bit Hamming comparisons really EVALUATED per second over all ranks, in
 G comps/s (whole step time, not kernel time).  The forward scan evaluates N1*N2 per
@@ -63,7 +73,8 @@ LANE_OPS_PER_COMP = 16
 CYC_XOR, CYC_BCNT = 2.32, 4.61
 PEAK_TLANEOPS = 1024 * 64 * F_MAX / (8 * CYC_XOR + 8 * CYC_BCNT) * LANE_OPS_PER_COMP / 1e12
 NOMINAL_TLANEOPS = 256 * 64 * F_MAX / 1e12  # 39.32, BASELINE.md 4
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r03", "r02")]  # the newest committed PMC summary wins
+KERNEL_SOURCES = ("mfma_scan.h", "vsmatch_kernels.h", "vsmatch.hip")  # what the committed counters were taken from
 BLOCK = 4096  # pairs per block of the block-cyclic partition (sfm_pairs.BLOCK)
 
 
@@ -81,8 +92,16 @@ def parse():
     ap.add_argument("--ratio", type=float, default=1.2)
     ap.add_argument("--seed", type=int, default=2025)
     ap.add_argument("--cpu-pairs", type=int, default=16384, help="CPU baseline sample (pairs); 0 = skip")
-    ap.add_argument("--cpu-threads", type=int, default=16,
-                    help="threads of the CPU baseline (16 = the host-core share of a 1-GPU box)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the CPU baseline; 0 = min(nproc, 16 x GPUs on the box): a GPU box gives each GPU 16 "
+                         "host cores, nproc may show the whole machine")
+    ap.add_argument("--cpu-pairs-multi", type=int, default=2048,
+                    help="with more than one rank: pairs of the GATHERED lists rank 0 checks against the CPU reference")
+    ap.add_argument("--workload", choices=("sfm", "nn2"), default="sfm",
+                    help="sfm = config 5 (all-pairs with cross-check, the headline); nn2 = config 4 (1M x 1M one direction)")
+    ap.add_argument("--nn2-size", type=int, default=1 << 20, help="--workload nn2: descriptors per side")
+    ap.add_argument("--no-strong-step", action="store_true",
+                    help="more than one rank, weak mode: skip the whole-list step reported as `strong_scaling`")
     ap.add_argument("--no-extra", action="store_true", help="skip the stereo-latency and 1M x 1M extras")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
@@ -166,15 +185,37 @@ def pair_of(k):
     return np.stack([i, j], axis=1).astype(np.uint32)
 
 
+def kernel_sources_sha256():
+    """sha256 over the kernel sources the library is built from: tools/summarize_prof.py writes it into
+    pmc_summary.json, so that counters taken from other code than the one running are marked stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "visual-slam_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def committed_counters():
     """Per-launch counters of the dominant kernel from the committed rocprofv3 --pmc passes
-    (tools/profile_bench.sh, profiles/r02/pmc_summary.json): HBM bytes per pair, sustained clock
-    and matrix-core busy share.  They cannot be read inside this process."""
-    try:
-        with open(os.path.join(PROFILE_DIR, "pmc_summary.json")) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    (tools/profile_bench.sh -> profiles/rNN/pmc_summary.json): HBM bytes per pair, sustained clock
+    and matrix-core busy share.  They cannot be read inside this process.  -> (summary, path, stale)."""
+    for d in PROFILE_DIRS:
+        try:
+            with open(os.path.join(d, "pmc_summary.json")) as f:
+                pmc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        try:
+            stale = pmc.get("kernel_sources_sha256") != kernel_sources_sha256()
+        except OSError:
+            stale = True
+        return pmc, os.path.relpath(os.path.join(d, "pmc_summary.json"), ROOT), stale
+    return None, None, True
+
+
+def default_cpu_threads(torch):
+    return max(1, min(os.cpu_count() or 1, 16 * max(1, torch.cuda.device_count())))
 
 
 def self_launch(a):
@@ -188,16 +229,9 @@ def self_launch(a):
     return subprocess.run(cmd).returncode
 
 
-def main():
-    a = parse()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(a))
-    import torch
-    import torch.distributed as dist
-    vsm = importlib.import_module("visual-slam_amd")
-    sfm_pairs = importlib.import_module("visual-slam_amd.sfm_pairs")
-    synth = vsm.synth
-
+def setup_ranks(a, torch, dist):
+    """One process per GPU: ranks from the launcher's environment, RCCL ("nccl") process group (gloo on CPU tensors
+    for --rehearse, every rank on cuda:0).  -> (world, rank, local, dev, coll_dev, multi)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -218,6 +252,132 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    return world, rank, local, dev, coll_dev, multi
+
+
+def main_nn2(a, torch, dist, vsm, sfm_pairs, world, rank, local, dev, coll_dev, multi):
+    """BASELINE.json config 4: n x n random 256-bit descriptors, one direction (keypoints.h:256-290): per query the
+    best index, best distance and second best distance.  Queries sharded over the ranks in contiguous blocks
+    (sfm_pairs.shard_range), the train set replicated by ONE broadcast, vsm_nn2_device per rank, ONE all-gather of the
+    three int32 arrays on the devices (every rank ends with the full result: the cross-check variant needs the other
+    direction's best index everywhere).  A step = the whole job incl. the all-gather: strong scaling."""
+    synth = vsm.synth
+    n = a.nn2_size
+    t_gen = time.perf_counter()
+    if rank == 0:
+        qa, tb = synth.planted_sets(n, a.seed + 2)
+    t_gen = time.perf_counter() - t_gen
+    t_bc = time.perf_counter()
+    if multi:
+        both = torch.empty((2, n, 4), dtype=torch.int64, device=coll_dev)
+        if rank == 0:
+            both[0].copy_(torch.from_numpy(qa.view(np.int64)))
+            both[1].copy_(torch.from_numpy(tb.view(np.int64)))
+        dist.broadcast(both, 0)  # queries travel too (32 MB): every rank cuts its own block out
+        both = both.to(dev)
+        dq, dtb = both[0], both[1]
+    else:
+        dq = torch.from_numpy(qa.view(np.int64)).to(dev)
+        dtb = torch.from_numpy(tb.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    t_bc = time.perf_counter() - t_bc
+    lo, hi = sfm_pairs.shard_range(n, rank, world)
+    per = (n + world - 1) // world
+    mine = torch.zeros((3, max(per, 1)), dtype=torch.int32, device=dev)
+    full = torch.empty((world * 3, max(per, 1)), dtype=torch.int32, device=coll_dev) if multi else None  # rank-major
+    m = vsm.Matcher(local)
+    m.set_variant(a.variant)
+
+    def step():
+        if hi > lo:
+            m.nn2_device(dq.data_ptr() + lo * 32, hi - lo, dtb.data_ptr(), n, mine[0].data_ptr(), mine[1].data_ptr(),
+                         mine[2].data_ptr())
+        if multi:
+            torch.cuda.synchronize()  # the matcher runs on a stream of its own
+            dist.all_gather_into_tensor(full, mine.cpu() if a.rehearse else mine)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    m.set_profiling(True)
+    scan_ms, launches = 0.0, 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        st = m.last_scan_stats()
+        scan_ms += st["scan_ms"]
+        launches += st["launches"]
+    barrier()
+    dt = time.perf_counter() - t0
+    m.set_profiling(False)
+    stats = torch.tensor([dt, scan_ms], dtype=torch.float64, device=coll_dev)
+    if multi:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dt = float(stats[0])
+    if rank != 0:
+        if multi:
+            dist.destroy_process_group()
+        return
+    res = (full.view(world, 3, -1).permute(1, 0, 2).reshape(3, -1)[:, :n] if multi else mine[:, :n]).cpu().numpy()
+    bi, bd, sd = res[0], res[1], res[2]
+    comps_rank = float(hi - lo) * n * a.steps
+    achieved = comps_rank * FLOP_PER_COMP / (scan_ms * 1e-3) / 1e12 if scan_ms else 0.0
+    # CPU leg (SURVEY 8d): a slice of queries, spread over every rank's block, against the whole train set on ONE core
+    from oracle import binding as _ob
+    n_slice = min(1024, n)
+    idx = np.unique(np.linspace(0, n - 1, n_slice).astype(np.int64))
+    t_cpu = time.perf_counter()
+    cbi, cbd, csd = _ob.port().nn2(np.ascontiguousarray(qa[idx]), tb)
+    t_cpu = time.perf_counter() - t_cpu
+    exact = bool(np.array_equal(cbi, bi[idx]) and np.array_equal(cbd, bd[idx]) and np.array_equal(csd, sd[idx]))
+    out = {
+        "metric": "hamming_comparisons_per_sec", "value": float(n) * n * a.steps / dt / 1e9, "unit": "Gcomp/s",
+        "n_gpus": world, "rehearsal_on_one_gpu": bool(a.rehearse), "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "fp4", "data": "synthetic",
+        "config": {"workload": "nn2_one_direction", "queries": n, "train": n,
+                   "sharding": f"queries in contiguous blocks over {world} rank(s), train set replicated by one broadcast, "
+                               "one all-gather of (best index, best distance, second distance)"},
+        "roofline": {"bound": "mfma", "kernel": "mfma_scan_kernel<8,1> (exact mode: start distance 256, train splits of <= 32768 rows)",
+                     "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
+                     "traffic": None, "launches": launches, "avg_launch_ms": scan_ms / max(1, launches),
+                     "kernel_gcomps": comps_rank / (scan_ms * 1e-3) / 1e9 if scan_ms else None,
+                     "note": "rank 0's scan launches, HIP events on the library's stream"},
+        "accepted_thr70_ratio1.2": int(((bd < 70) & (1.2 * bd <= sd)).sum()),
+        "cpu_baseline": {"value": len(idx) * float(n) / t_cpu / 1e9, "unit": "Gcomp/s", "cores": 1, "kind": "port",
+                         "sample": f"{len(idx)} queries spread over the whole query set x {n} train descriptors, {t_cpu:.1f} s on 1 core "
+                                   f"(extrapolates to {t_cpu * n / len(idx) / 3600:.2f} core-hours for the whole job)",
+                         "nproc": os.cpu_count(), "cpu_model": cpu_model(), "gpu_lists_bit_exact": exact},
+        "setup": {"generate_s": t_gen, "broadcast_or_upload_s": t_bc},
+    }
+    print(json.dumps(out), flush=True)
+    if multi:
+        dist.destroy_process_group()
+    if not exact:
+        raise SystemExit("bench.py: GPU 2-NN results differ from the CPU port on the checked slice")
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a))
+    import torch
+    import torch.distributed as dist
+    vsm = importlib.import_module("visual-slam_amd")
+    sfm_pairs = importlib.import_module("visual-slam_amd.sfm_pairs")
+    synth = vsm.synth
+
+    if a.cpu_threads <= 0:
+        a.cpu_threads = default_cpu_threads(torch)
+    world, rank, local, dev, coll_dev, multi = setup_ranks(a, torch, dist)
+    if a.workload == "nn2":
+        return main_nn2(a, torch, dist, vsm, sfm_pairs, world, rank, local, dev, coll_dev, multi)
 
     # ---- database: rank 0 generates, one broadcast replicates (RCCL over xGMI) -------------
     t_gen = time.perf_counter()
@@ -348,6 +508,96 @@ def main():
         if a.strong:
             gathered_ok = gathered_ok and int(g_off[-1]) == int(round(matches_all / a.steps))
 
+    # ---- more than one rank, weak mode: ONE whole-list step as well (strong scaling, north_star's ">= 7x at 8
+    # GPUs"): the whole all-pairs list dealt block-cyclically, every rank's share in one call, the gather to
+    # rank 0 device to device -- what `--strong` times as its step, here once, after one untimed call
+    strong_info, strong_gathered = None, None
+    if multi and not a.strong and not a.no_strong_step:
+        mine = sfm_pairs.shard_indices(total_pairs, rank, world, BLOCK)
+        Ps = len(mine)
+        s_pairs = torch.from_numpy(pair_of(mine).view(np.int32).copy()).to(dev)
+        s_offsets = torch.empty(Ps + 1, dtype=torch.int64, device=dev)
+        s_cap = [max(4 * Ps, 1 << 16)]
+        s_out = [torch.empty((s_cap[0], 2), dtype=torch.int32, device=dev)]
+
+        def run_whole():
+            while True:
+                try:
+                    return m.match_pairs_device(s_pairs.data_ptr(), Ps, a.threshold, a.ratio, s_offsets.data_ptr(),
+                                                s_out[0].data_ptr(), s_cap[0])
+                except vsm.VsmError as e:  # a share with more matches than guessed
+                    if e.code != vsm.matcher.VSM_ERR_CAPACITY:
+                        raise
+                    s_cap[0] *= 2
+                    s_out[0] = torch.empty((s_cap[0], 2), dtype=torch.int32, device=dev)
+
+        def gather_whole(tot):
+            counts, lists = s_offsets[1:] - s_offsets[:-1], s_out[0][:tot]
+            if a.rehearse:
+                counts, lists = counts.cpu(), lists.cpu()
+            return sfm_pairs.gather_matches(counts, lists, total_pairs, block=BLOCK)
+
+        gather_whole(run_whole())  # untimed: work buffers of this size, capacity, the collectives' buffers
+        barrier()
+        ts = time.perf_counter()
+        tot_s = run_whole()
+        torch.cuda.synchronize()
+        t_match = time.perf_counter() - ts
+        strong_gathered = gather_whole(tot_s)
+        barrier()
+        t_whole = time.perf_counter() - ts
+        tm = torch.tensor([t_match, float(tot_s)], dtype=torch.float64, device=coll_dev)
+        tsum = tm.clone()
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            one = None
+            if (a.images, a.desc, a.threshold, a.ratio) == (5000, 2000, 70, 1.2):
+                for d in PROFILE_DIRS:  # the same step on ONE rank (bench.py --strong), committed
+                    try:
+                        with open(os.path.join(d, "bench_strong_one_rank.json")) as f:
+                            one = (json.loads(f.readline())["ms_per_step"] / 1e3, os.path.relpath(os.path.join(d, "bench_strong_one_rank.json"), ROOT))
+                        break
+                    except (OSError, ValueError, KeyError):
+                        continue
+            so, sl = strong_gathered
+            strong_info = {
+                "workload": "the WHOLE all-pairs list sharded block-cyclically over the ranks + the gather of every list to rank 0 "
+                            "(what --strong times as its step), once, after one untimed call",
+                "pairs": total_pairs, "seconds": t_whole, "pairs_per_s": total_pairs / t_whole,
+                "match_seconds_max_over_ranks": float(tm[0]), "gather_ms": (t_whole - float(tm[0])) * 1e3,
+                "matches": int(tsum[1]),
+                "gathered_lists_consistent": bool(int(so[-1]) == len(sl) == int(tsum[1]) and bool((so[1:] >= so[:-1]).all())),
+                "one_rank_seconds": one[0] if one else None, "speedup_vs": one[1] if one else None,
+                "speedup": (one[0] / t_whole) if one else None,
+            }
+
+    # ---- more than one rank: rank 0 holds the reference against a bounded sample of the GATHERED lists, spread
+    # evenly over the list and so over every rank's blocks (src/sfm.cpp:1295-1321 is the loop being replaced)
+    multi_check = None
+    if multi and rank == 0 and gathered is not None and a.cpu_pairs > 0 and a.cpu_pairs_multi > 0:
+        def sample_of(g, all_pairs_fn, n_all, n_take):
+            g_off, g_lists = g
+            idx = np.unique(np.linspace(0, n_all - 1, min(n_take, n_all)).astype(np.int64))
+            oh = g_off.cpu().numpy()
+            return all_pairs_fn(idx), [g_lists[int(oh[k]): int(oh[k + 1])].cpu().numpy() for k in idx.tolist()]
+
+        if a.strong:
+            spairs, slists = sample_of(gathered, pair_of, total_pairs, a.cpu_pairs_multi)
+        else:  # the last step's batches of the ranks, rank after rank
+            s_last = n_steps - 1
+            firsts = [((s_last * world + r) * P) % max(1, total_pairs - P + 1) for r in range(world)]
+            spairs, slists = sample_of(gathered, lambda idx: pair_of(np.asarray(firsts)[idx // P] + idx % P), P * world,
+                                       a.cpu_pairs_multi)
+        multi_check = cpu_baseline(db, off, spairs, a.threshold, a.ratio, a.cpu_threads, slists)
+        multi_check["sample"] = ("GATHERED lists on rank 0: " + multi_check["sample"] + "; pairs spread evenly over the "
+                                 f"{'whole list' if a.strong else 'last step'} and so over every rank's blocks")
+        if strong_gathered is not None:
+            p2, l2 = sample_of(strong_gathered, pair_of, total_pairs, max(1, a.cpu_pairs_multi // 4))
+            chk = cpu_baseline(db, off, p2, a.threshold, a.ratio, a.cpu_threads, l2)
+            strong_info["sample_pairs_checked_against_cpu_" + chk["kind"]] = len(p2)
+            strong_info["gpu_lists_bit_exact"] = chk["gpu_lists_bit_exact"]
+
     if rank != 0:
         if multi:
             dist.destroy_process_group()
@@ -383,13 +633,17 @@ def main():
         "evaluated_over_reference_equivalent": scan_comps / comps_rank,
         "hbm_algorithmic_bytes_per_pair": int(32 * 2 * a.desc),
     }
-    pmc = committed_counters()
+    pmc, pmc_path, stale = committed_counters()
     if pmc:  # from the committed PMC passes of the same command (they cannot be read in-process)
         roofline["traffic"] = pmc["hbm_bytes_per_pair"] * min(P, 32768)
         roofline["sustained_clock_ghz"] = pmc["sustained_clock_ghz"]
         roofline["mfma_busy_frac"] = pmc["mfma_busy_frac"]
-        roofline["frac_of_peak_at_sustained_clock"] = roofline["frac"] * (F_MAX / 1e9) / pmc["sustained_clock_ghz"]
-        roofline["counters_source"] = ("profiles/r02/pmc_summary.json: rocprofv3 --pmc passes of tools/profile_bench.sh at this "
+        # taken from other kernel code than the one running (sha256 over csrc/{mfma_scan.h, vsmatch_kernels.h, vsmatch.hip}
+        # recorded by tools/summarize_prof.py): the counters describe the profiled build, not this run
+        roofline["counters_stale"] = bool(stale)
+        if not stale:
+            roofline["frac_of_peak_at_sustained_clock"] = roofline["frac"] * (F_MAX / 1e9) / pmc["sustained_clock_ghz"]
+        roofline["counters_source"] = (pmc_path + ": rocprofv3 --pmc passes of tools/profile_bench.sh at this "
                                        "command's launch size (FETCH_SIZE x 2 + WRITE_SIZE per pair x pairs per launch; "
                                        "GRBM_GUI_ACTIVE / XCDs / duration; SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / (GRBM_GUI_ACTIVE / XCDs))")
     out = {
@@ -411,6 +665,8 @@ def main():
                   "gather": ("inside every timed step" if a.strong and multi else
                              "timed apart from the steps" if multi else "single rank: nothing to gather")},
     }
+    if strong_info is not None:
+        out["strong_scaling"] = strong_info
 
     if world == 1 and not a.no_extra and not a.strong and not (a.variant & 0x2000000):
         # The same batch on the popcount (v_xor + v_bcnt) form of the scan, the formulation
@@ -447,7 +703,9 @@ def main():
             "lists_identical_to_matrix_core_path": same,
         }
 
-    if a.cpu_pairs > 0 and world == 1:
+    if multi_check is not None:
+        out["cpu_baseline"] = multi_check
+    elif a.cpu_pairs > 0 and world == 1:
         n_cpu = min(a.cpu_pairs, P)
         s = 0 if a.strong else n_steps - 1
         offs_h = d_offsets[: n_cpu + 1].cpu().numpy()
@@ -457,6 +715,8 @@ def main():
                                            a.cpu_threads, gpu_lists)
     else:
         out["cpu_baseline"] = None
+    if out["cpu_baseline"] is not None:
+        out["cpu_baseline"]["threads_default_rule"] = "min(nproc, 16 x GPUs on the box) unless --cpu-threads says otherwise"
 
     if not a.no_extra and world == 1 and not a.strong:
         extra = {}
@@ -835,9 +1095,14 @@ def main():
                               "bit_exact_vs_cpu_on_slice": nn2_exact}
         out["extra"] = extra
 
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+    # a list that differs from the reference's fails the run, after the line is out
+    bad = [k for k, v in (("cpu_baseline", out.get("cpu_baseline")), ("strong_scaling", out.get("strong_scaling")))
+           if v and v.get("gpu_lists_bit_exact") is False]
+    if bad:
+        raise SystemExit(f"bench.py: GPU lists differ from the CPU reference ({', '.join(bad)})")
 
 
 if __name__ == "__main__":

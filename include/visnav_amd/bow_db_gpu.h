@@ -53,6 +53,37 @@ class BowDatabaseGpu {
   using BowQueryResult = std::vector<std::pair<FrameCamIdT, double>>;  // common_types.h:333
 
   BowDatabaseGpu() : id_(vsm_detail::next_bowdb_id()) {}
+  // The reference's BowDatabase is freely copyable.  A copy is a database of its own from then on: it gets a
+  // fresh id, so that the (id, version) a thread's context remembers can never name two objects whose contents
+  // have since diverged (both would otherwise be queried against whichever was uploaded first).
+  BowDatabaseGpu(const BowDatabaseGpu& o)
+      : keys_(o.keys_), off_(o.off_), words_(o.words_), values_(o.values_), id_(vsm_detail::next_bowdb_id()) {}
+  BowDatabaseGpu(BowDatabaseGpu&& o) noexcept
+      : keys_(std::move(o.keys_)), off_(std::move(o.off_)), words_(std::move(o.words_)), values_(std::move(o.values_)),
+        id_(vsm_detail::next_bowdb_id()) {
+    o.clear();
+  }
+  BowDatabaseGpu& operator=(const BowDatabaseGpu& o) {
+    if (this != &o) {
+      keys_ = o.keys_;
+      off_ = o.off_;
+      words_ = o.words_;
+      values_ = o.values_;
+      version_++;  // same object, new contents
+    }
+    return *this;
+  }
+  BowDatabaseGpu& operator=(BowDatabaseGpu&& o) noexcept {
+    if (this != &o) {
+      keys_ = std::move(o.keys_);
+      off_ = std::move(o.off_);
+      words_ = std::move(o.words_);
+      values_ = std::move(o.values_);
+      version_++;
+      o.clear();
+    }
+    return *this;
+  }
 
   void insert(const FrameCamIdT& fcid, const BowVector& bow_vector) {
     keys_.push_back(fcid);

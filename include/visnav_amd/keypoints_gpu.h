@@ -61,33 +61,59 @@ inline vsm_ctx* thread_context() {
 }
 
 // One context per GPU of VSM_DEVICES, created on first use, shared by the process.
+// The pool has NO destructor and is never freed at exit: a function-local static built before the
+// process's first HIP call is destroyed AFTER the HIP runtime's own exit handlers have run, and
+// vsm_destroy (hipStreamSynchronize / hipFree / hipStreamDestroy) on a runtime that is already torn down
+// aborts (seen as a failed `dev_runtime_unloaded` check under __cxa_finalize of libamdhip64 in the two-context
+// sanitizer run of tools/asan_run.sh).  The driver reclaims the contexts' device memory with the process;
+// a caller that wants them gone earlier calls visnav::vsm_detail::shutdown_device_pool() before exit.
 struct DevicePool {
   std::vector<vsm_ctx*> ctxs;
   std::mutex mu;
-  ~DevicePool() {
-    for (vsm_ctx* c : ctxs) vsm_destroy(c);
-  }
+  bool ready = false;
 };
 
 inline DevicePool& device_pool() {
-  static DevicePool pool;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    const char* list = std::getenv("VSM_DEVICES");
-    if (!list || !*list) return;
+  static DevicePool* pool = new DevicePool;  // leaked on purpose, see above
+  std::lock_guard<std::mutex> lk(pool->mu);
+  if (pool->ready) return *pool;
+  const char* list = std::getenv("VSM_DEVICES");
+  if (list && *list) {
     thread_context();  // the layout probe
+    std::vector<vsm_ctx*> made;  // swapped in only when every context exists: a failure leaves no partial list behind
     for (const char* p = list; *p;) {
       char* end = nullptr;
       const long dev = std::strtol(p, &end, 10);
       if (end == p) break;
       vsm_ctx* c = nullptr;
-      if (vsm_create(int(dev), &c) != VSM_OK)
-        throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (VSM_DEVICES): ") + vsm_last_error());
-      pool.ctxs.push_back(c);
+      if (vsm_create(int(dev), &c) != VSM_OK) {
+        const std::string why = vsm_last_error();
+        for (vsm_ctx* m : made) vsm_destroy(m);
+        throw std::runtime_error("visnav::matchDescriptorsBatch (VSM_DEVICES): " + why);  // not ready: the next call tries again
+      }
+      made.push_back(c);
       p = *end == ',' ? end + 1 : end;
     }
-  });
-  return pool;
+    pool->ctxs.swap(made);
+  }
+  pool->ready = true;
+  return *pool;
+}
+
+// Destroys the pool's contexts while the HIP runtime is still up (optional; call it before main returns).
+inline void shutdown_device_pool() {
+  DevicePool& pool = device_pool();
+  std::lock_guard<std::mutex> lk(pool.mu);
+  for (vsm_ctx* c : pool.ctxs) vsm_destroy(c);
+  pool.ctxs.clear();
+  pool.ready = false;
+}
+
+// Image pairs per library call of matchDescriptorsBatch (VSM_BATCH_PAIRS overrides it: a test hook).
+inline size_t batch_chunk_pairs() {
+  const char* e = std::getenv("VSM_BATCH_PAIRS");
+  const long v = e ? std::atol(e) : 0;
+  return v > 0 ? size_t(v) : size_t(262144);
 }
 
 }  // namespace vsm_detail
@@ -121,7 +147,8 @@ inline void matchDescriptorsBatch(const std::vector<const std::vector<std::bitse
                                   const std::vector<std::pair<int, int>>& ids_to_match,
                                   std::vector<std::vector<std::pair<int, int>>>& out, int threshold,
                                   double dist_2_best) {
-  out.assign(ids_to_match.size(), {});
+  out.clear();
+  out.resize(ids_to_match.size());
   std::vector<uint32_t> offsets(sets.size() + 1, 0);
   for (size_t i = 0; i < sets.size(); i++) offsets[i + 1] = offsets[i] + uint32_t(sets[i]->size());
   std::vector<uint64_t> flat(size_t(offsets.back()) * 4);
@@ -131,36 +158,57 @@ inline void matchDescriptorsBatch(const std::vector<const std::vector<std::bitse
                 reinterpret_cast<const uint64_t*>(sets[i]->data()) + sets[i]->size() * 4,
                 flat.begin() + size_t(offsets[i]) * 4);
   std::vector<uint32_t> pairs(ids_to_match.size() * 2);
-  size_t cap = 0;
   for (size_t k = 0; k < ids_to_match.size(); k++) {
     const int a = ids_to_match[k].first, b = ids_to_match[k].second;
     if (a < 0 || b < 0 || size_t(a) >= sets.size() || size_t(b) >= sets.size())
       throw std::runtime_error("visnav::matchDescriptorsBatch: image index out of range");
     pairs[2 * k] = uint32_t(a);
     pairs[2 * k + 1] = uint32_t(b);
-    cap += std::min(sets[a]->size(), sets[b]->size());
   }
-  std::vector<uint64_t> offs(ids_to_match.size() + 1);
-  std::vector<std::pair<int, int>> all(cap ? cap : 1);
-  size_t total = 0;
   vsm_detail::DevicePool& pool = vsm_detail::device_pool();
-  if (!pool.ctxs.empty()) {
-    // all the GPUs of VSM_DEVICES: database replicated device to device, pairs dealt in blocks, one
-    // host thread per GPU inside the library (vsm_match_pairs_multi); the pool serves one batch at a time
-    std::lock_guard<std::mutex> lk(pool.mu);
-    if (vsm_db_upload_multi(pool.ctxs.data(), pool.ctxs.size(), flat.data(), offsets.data(), sets.size()) != VSM_OK ||
-        vsm_match_pairs_multi(pool.ctxs.data(), pool.ctxs.size(), pairs.data(), ids_to_match.size(), threshold,
-                              dist_2_best, offs.data(), reinterpret_cast<int32_t*>(all.data()), all.size(), &total) != VSM_OK)
+  const bool multi = !pool.ctxs.empty();
+  // the pool serves one batch at a time (database replicated device to device, pairs dealt in blocks, one host
+  // thread per GPU inside the library: vsm_match_pairs_multi)
+  std::unique_lock<std::mutex> lk(pool.mu, std::defer_lock);
+  vsm_ctx* ctx = nullptr;
+  if (multi) {
+    lk.lock();
+    if (vsm_db_upload_multi(pool.ctxs.data(), pool.ctxs.size(), flat.data(), offsets.data(), sets.size()) != VSM_OK)
       throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPUs of VSM_DEVICES): ") + vsm_last_error());
   } else {
-    vsm_ctx* ctx = vsm_detail::thread_context();
-    if (vsm_db_upload(ctx, flat.data(), offsets.data(), sets.size()) != VSM_OK ||
-        vsm_match_pairs(ctx, pairs.data(), ids_to_match.size(), threshold, dist_2_best, offs.data(),
-                        reinterpret_cast<int32_t*>(all.data()), all.size(), &total) != VSM_OK)
+    ctx = vsm_detail::thread_context();
+    if (vsm_db_upload(ctx, flat.data(), offsets.data(), sets.size()) != VSM_OK)
       throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPU): ") + vsm_last_error());
   }
-  for (size_t k = 0; k < ids_to_match.size(); k++)
-    out[k].assign(all.begin() + offs[k], all.begin() + offs[k + 1]);
+  std::vector<uint64_t>().swap(flat);  // the database is on the device(s) now
+  // The pair list goes through in chunks, each with a list buffer sized by what real data needs (32 matches per
+  // pair to begin with) instead of the worst case min(n1, n2) per pair -- 16 KB per pair of 2000-descriptor images,
+  // 200 GB for the 12.5 M pairs of a 5000-image match_all.  A chunk that needs more says how much
+  // (VSM_ERR_CAPACITY returns the exact total) and runs once more with that.  Host memory: the chunk buffer
+  // (<= max(64 K, what a chunk really holds) x 8 B) + the lists handed back in `out`; device memory likewise.
+  const size_t chunk_pairs = vsm_detail::batch_chunk_pairs();
+  std::vector<uint64_t> offs;
+  std::vector<std::pair<int, int>> all;
+  for (size_t k0 = 0; k0 < ids_to_match.size(); k0 += chunk_pairs) {
+    const size_t n = std::min(chunk_pairs, ids_to_match.size() - k0);
+    size_t bound = 0;  // the cross-check emits at most min(n1, n2) pairs per image pair
+    for (size_t k = k0; k < k0 + n; k++) bound += std::min(sets[pairs[2 * k]]->size(), sets[pairs[2 * k + 1]]->size());
+    size_t cap = std::min(bound, std::max<size_t>(size_t(1) << 16, 32 * n));
+    offs.resize(n + 1);
+    for (int attempt = 0;; attempt++) {
+      if (all.size() < std::max<size_t>(cap, 1)) all.resize(std::max<size_t>(cap, 1));
+      size_t total = 0;
+      const int rc = multi ? vsm_match_pairs_multi(pool.ctxs.data(), pool.ctxs.size(), pairs.data() + 2 * k0, n, threshold, dist_2_best,
+                                                   offs.data(), reinterpret_cast<int32_t*>(all.data()), cap, &total)
+                           : vsm_match_pairs(ctx, pairs.data() + 2 * k0, n, threshold, dist_2_best, offs.data(),
+                                             reinterpret_cast<int32_t*>(all.data()), cap, &total);
+      if (rc == VSM_OK) break;
+      if (rc != VSM_ERR_CAPACITY || attempt > 0 || total <= cap)
+        throw std::runtime_error(std::string("visnav::matchDescriptorsBatch (GPU): ") + vsm_last_error());
+      cap = total;  // exact: the second attempt fits
+    }
+    for (size_t k = 0; k < n; k++) out[k0 + k].assign(all.begin() + offs[k], all.begin() + offs[k + 1]);
+  }
 }
 
 }  // namespace visnav

@@ -79,6 +79,19 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "FAIL: insert after clear\n");
       return 1;
     }
+    // a copy is a database of its own (the reference's BowDatabase is copyable): after different inserts into
+    // the original and the copy each answers from its own contents, whichever this thread's context saw last
+    Db copy = db;
+    db.insert(FrameCamId{43, 0}, bows[2]);
+    copy.insert(FrameCamId{77, 1}, bows[3]);
+    r.clear();
+    db.query(bows[2], 1, r);
+    Db::BowQueryResult rc;
+    copy.query(bows[3], 1, rc);
+    if (r.size() != 1 || r[0].first.frame_id != 43 || rc.size() != 1 || rc[0].first.frame_id != 77) {
+      std::fprintf(stderr, "FAIL: a copy and its original answer from one device database\n");
+      return 1;
+    }
     std::printf("bowdb shim ok: %zu images, %zu pairs\n", n, want.size() / 2);
     return 0;
   } catch (const std::exception& e) {

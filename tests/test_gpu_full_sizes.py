@@ -236,3 +236,54 @@ def test_attach_again_after_rewriting_the_buffer():
                 i, j = pairs[k]
                 want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
                 assert np.array_equal(lists[int(offs[k]):int(offs[k + 1])], want), (k, i, j)
+
+
+def test_cpp_batch_of_200k_pairs_within_a_memory_bound(tmp_path):
+    """matchDescriptorsBatch (the C++ drop-in for match_all, src/sfm.cpp:1276-1321) at config-5
+    SHAPE -- 640 images x 2000 descriptors, all 204 480 pairs -- from the C++ binary.  A worst-case list buffer would
+    be 204 480 x 2000 x 8 B = 3.3 GB of host memory (200 GB for the full 5000 images); the shim now sends the pair list
+    through in chunks with buffers sized by the data.  Peak resident set under 2 GB; the lists of the single-context
+    run and of the two-context run (vsm_match_pairs_multi) are identical (checksum over every list, in order), also
+    with small chunks that force the capacity retry; every 997th pair against the oracle."""
+    import subprocess
+    root = os.path.dirname(cases.GOLDEN.rstrip("/"))
+    exe = os.path.join(root, "cpp", "shim_batch_big_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    n_img, per, every = 640, 2000, 997
+    db, off = cases.synth.sfm_database(n_img, per, seed=31, share_frac=0.4, window=8)
+    path = tmp_path / "db.bin"
+    db.tofile(path)
+    lines = {}
+    for name, extra in (("single", {}), ("two_contexts", {"VSM_DEVICES": "0,0"}),
+                        ("small_chunks", {"VSM_BATCH_PAIRS": "50000"})):
+        env = dict(os.environ)
+        env.pop("VSM_DEVICES", None)
+        env.pop("VSM_BATCH_PAIRS", None)
+        env.update(extra)
+        smp = tmp_path / (name + ".bin")
+        r = subprocess.run([exe, str(path), str(n_img), str(per), str(every), str(smp)], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = r.stdout.split()
+        lines[name] = dict(zip(f[0::2], f[1::2]))
+        assert int(lines[name]["pairs"]) == n_img * (n_img - 1) // 2 >= 200000
+        assert int(lines[name]["peak_rss_mb"]) < 2048, lines[name]
+    assert lines["single"]["checksum"] == lines["two_contexts"]["checksum"] == lines["small_chunks"]["checksum"]
+    assert int(lines["single"]["matches"]) > 100000
+    rec = np.fromfile(tmp_path / "single.bin", dtype=np.int32)
+    port = binding.port()
+    pos, seen = 0, 0
+    while pos < len(rec):
+        k, cnt = int(rec[pos]), int(rec[pos + 1])
+        got = rec[pos + 2: pos + 2 + 2 * cnt].reshape(-1, 2)
+        pos += 2 + 2 * cnt
+        i = int((1 + np.sqrt(1 + 8 * k)) // 2)
+        while i * (i - 1) // 2 > k:
+            i -= 1
+        while (i + 1) * i // 2 <= k:
+            i += 1
+        j = k - i * (i - 1) // 2
+        want = port.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(got, want), (k, i, j)
+        seen += 1
+    assert seen == (n_img * (n_img - 1) // 2 + every - 1) // every

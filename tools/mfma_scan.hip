@@ -269,7 +269,8 @@ int main(int argc, char** argv) {
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
-  const V vs[] = {{"shipped NB8", 24, 8}, {"shipped NB4", 24, 4}, {"shipped NB2", 24, 2},
+  const V vs[] = {{"shipped NB8", 24, 8}, {"zero-rich codes NB8", 64, 8}, {"shipped NB8", 24, 8}, {"zero-rich codes NB8", 64, 8},
+                  {"shipped NB4", 24, 4}, {"zero-rich codes NB4", 64, 4}, {"shipped NB2", 24, 2}, {"zero-rich codes NB2", 64, 2},
                   {"NB8, 4-wave workgroups", 44, 8}, {"NB4, 4-wave workgroups", 44, 4},
                   {"EXPERIMENT: LDS-shared operands, 8 waves", 54, 8}, {"EXPERIMENT: LDS-shared operands, 4 waves", 54, 4},
                   {"EXPERIMENT: LDS-shared, 4 waves x 2 steps", 54, 2}, {"shipped NB8 again", 24, 8}};
@@ -299,12 +300,17 @@ int main(int argc, char** argv) {
       if (v.fmt == 44) {  // tiles of a job in one workgroup (one CU: they share its L1), job-minor order
         const dim3 g4(n_jobs * ((tiles + 3) / 4)), b4(256);
 #define ARGS4 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, 0u, d_lim
-        if (v.nb == 8) mfma_scan_kernel<8, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
-        else mfma_scan_kernel<4, 4><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
+        if (v.nb == 8) mfma_scan_kernel<8, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
+        else mfma_scan_kernel<4, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
       } else
-      if (v.nb == 8) mfma_scan_kernel<8, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
-      else if (v.nb == 4) mfma_scan_kernel<4, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
-      else mfma_scan_kernel<2, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+      if (v.fmt == 64) {
+        if (v.nb == 8) mfma_scan_kernel<8, 1, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+        else if (v.nb == 4) mfma_scan_kernel<4, 1, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+        else mfma_scan_kernel<2, 1, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+      } else
+      if (v.nb == 8) mfma_scan_kernel<8, 1, 0><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+      else if (v.nb == 4) mfma_scan_kernel<4, 1, 0><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
+      else mfma_scan_kernel<2, 1, 0><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
 #else
       if (v.fmt == 4 && v.nb == 8) mfma_scan_kernel<4, 8><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
       else if (v.fmt == 4) mfma_scan_kernel<4, 4><<<g, blk>>>(ARGS, nullptr, AcceptMask{nullptr, 0, nullptr});
@@ -321,7 +327,7 @@ int main(int argc, char** argv) {
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
     }
-    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54) {
+    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64) {
       CK(hipEventRecord(e0));
       refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr);
       CK(hipEventRecord(e1));

@@ -2,6 +2,7 @@
 """Turns the rocprofv3 rocpd databases written by tools/profile_bench.sh into the
 text summaries committed under profiles/ and into pmc_summary.json, which bench.py reads for
 roofline.traffic / sustained_clock_ghz / mfma_busy_frac.  usage: summarize_prof.py <prof dir> <out dir>"""
+import hashlib
 import json
 import os
 import sqlite3
@@ -93,6 +94,49 @@ if g and b:
 v = ctr.get(("pmc_sq", "SQ_INSTS_VALU"))
 if v and s.get("SQ_INSTS_MFMA_per_launch"):
     s["valu_instructions_per_mfma"] = v / s["SQ_INSTS_MFMA_per_launch"]
+# what code the counters were taken from: bench.py marks them stale when the sources have changed since
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for name in ("mfma_scan.h", "vsmatch_kernels.h", "vsmatch.hip"):
+    with open(os.path.join(ROOT, "visual-slam_amd", "csrc", name), "rb") as f:
+        h.update(f.read())
+s["kernel_sources_sha256"] = h.hexdigest()
+s["kernel_sources"] = "visual-slam_amd/csrc/{mfma_scan.h, vsmatch_kernels.h, vsmatch.hip}, concatenated in this order"
+
+# the popcount formulation (north_star's: v_xor + v_bcnt, knob bit 25) under the same command: VALU utilisation evidence
+pc = {}
+POP = "scan_kernel_adaptive"
+for d in ("pop_trace", "pop_sq", "pop_fetch", "pop_write"):
+    p = os.path.join(src, d, "p_results.db" if d != "pop_trace" else "t_results.db")
+    if not os.path.exists(p):
+        continue
+    if d == "pop_trace":
+        rows = q(p, f"select start, end from kernels where name like '%{POP}%' order by start")
+        durs_p = [(e - b) / 1e3 for b, e in rows][warm:]
+        if durs_p:
+            pc["avg_launch_us_kernel_trace"] = sum(durs_p) / len(durs_p)
+        continue
+    rows = q(p, f"select dispatch_id, counter_name, value, end - start from counters_collection where kernel_name like '%{POP}%' order by dispatch_id")
+    ids = sorted({r[0] for r in rows})[warm:]
+    for c in {r[1] for r in rows}:
+        vals = [r[2] for r in rows if r[1] == c and r[0] in ids]
+        if vals:
+            pc[c] = sum(vals) / len(vals)
+    if d == "pop_sq" and rows:
+        clk = [r[2] / XCDS / r[3] for r in rows if r[1] == "GRBM_GUI_ACTIVE" and r[0] in ids]
+        if clk:
+            pc["sustained_clock_ghz"] = sum(clk) / len(clk)
+if pc:
+    if "SQ_ACTIVE_INST_VALU" in pc and "GRBM_GUI_ACTIVE" in pc:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md): x4 / SIMDs / cycles per XCD
+        pc["valu_busy_frac"] = pc["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / (pc["GRBM_GUI_ACTIVE"] / XCDS)
+    if "FETCH_SIZE" in pc and "WRITE_SIZE" in pc:
+        pc["hbm_bytes_per_pair"] = (2 * pc["FETCH_SIZE"] + pc["WRITE_SIZE"]) * 1024 / pairs
+    if "SQ_INSTS_VALU" in pc:
+        pc["valu_instructions_per_wave_comparison"] = pc["SQ_INSTS_VALU"] / (pairs * float(line["config"]["desc_per_image"]) ** 2 / 64)
+    pc["command"] = cmd + " --variant 0x2000000"
+    s["popcount_path"] = pc
+
 s["note"] = ("rocprofv3 --pmc, one pass per counter group (tools/profile_bench.sh); raw FETCH_SIZE / WRITE_SIZE in KiB. "
              "hbm_bytes_per_pair = (2 x FETCH_SIZE + WRITE_SIZE) / pairs: the x2 gfx950 correction of MI355X_MICROARCH.md "
              "(FETCH_SIZE reports half the bytes of 16 B/lane global loads) applies, the scan reads every descriptor through "

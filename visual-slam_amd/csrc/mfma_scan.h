@@ -87,6 +87,39 @@ __device__ __forceinline__ i32x8 expand_bits_r(u32 w, u32 m88, u32 c22) {
   return v;
 }
 
+// CODES 1, the shift-free "zero-rich" train codes (round 3).  A train code need not be symmetric: with the
+// QUERY code of a bit symmetric (+-g), a train bit may take any two values {mu - delta, mu + delta}: the sum
+// over k of query x train is then  sum_k (+-g mu)  +  g delta (256 - 2 d)  -- a constant of the QUERY (which
+// rides in the lane's start value of best / second, a lane of the result holds one query) plus the distance,
+// as long as g delta is the same for every bit.  e2m1 has such pairs for every bit of a nibble WITHOUT moving
+// the bit: bit 3 (the sign) of code 0x1: +0.5 / -0.5; bit 2 alone: 0 / 2.0; bit 1 alone: 0 / 1.0; bit 0 alone:
+// 0 / 0.5 -- with query codes +-1.0, +-0.5, +-1.0, +-2.0 for the four bit classes every product of differing
+// bits is +0.5 (or 0 and +-0.5 / +-1 ... the constant part), g delta = 0.5.  So register s of a train word is
+// just  w & (0x88888888 >> s)  (| 0x11111111 for s = 0): 16 instructions per 32 train rows instead of 28, and
+// three eighths of the train codes are ZERO -- less switching in the multipliers, which is what holds the clock
+// down under this kernel.  Result: D' = 768 + i ulp + C_q + d - 128 with C_q = 96 - P, P = the number of one
+// bits of the query outside the sign class (w & 0x77777777): everything in [544, 992], inside the binade
+// [512, 1024) whose ulp is 2^-14; every partial sum is a multiple of 0.5 (+ the tag) of magnitude <= 224
+// around 768: exact.  Bit pattern: Z_q + (d << 14 | tag), Z_q = 0x44000000 + ((224 - P) << 14).
+__device__ __forceinline__ i32x8 expand_train_zr(u32 w, u32 m88, u32 c11, u32 m44, u32 m22, u32 m11) {
+  i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  v[0] = (int)((w & m88) | c11);
+  v[1] = (int)(w & m44);
+  v[2] = (int)(w & m22);
+  v[3] = (int)(w & m11);
+  return v;
+}
+// the query side of CODES 1 (once per tile): sign class 0x2 | ~bit << 3 (+-1.0), then 0x1 (0.5), 0x2 (1.0),
+// 0x4 (2.0) | bit << 3
+__device__ __forceinline__ i32x8 expand_query_zr(u32 w) {
+  i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  v[0] = (int)((~w & 0x88888888u) | 0x22222222u);
+  v[1] = (int)(((w << 1) & 0x88888888u) | 0x11111111u);
+  v[2] = (int)(((w << 2) & 0x88888888u) | 0x22222222u);
+  v[3] = (int)(((w << 3) & 0x88888888u) | 0x44444444u);
+  return v;
+}
+
 // cbsz = blgp = 4: FP4 e2m1 operands (FP8 e4m3 runs at half the rate with twice the registers:
 // 5.9 against 9.6 T with the first version of this kernel).  Scale operands 0 / 0: the compiler emits
 // v_mfma_f32_32x32x64_f8f6f4, no block scales, so a product is +-1/4.
@@ -117,6 +150,9 @@ __device__ __forceinline__ void store_accept_mask(const AcceptMask& acc, const J
 constexpr int GROUP_D_BASE = 0x43000000;  // bits of 128.0 = D' of distance 0
 constexpr int GROUP_D_256 = 0x43800000;   // bits of 256.0 = D' of distance 256
 constexpr int GROUP_D_START = 0x43400000; // bits of 192.0 = the accumulators' start value (+ i ulp)
+constexpr int ZR_START = 0x44400000;      // CODES 1: bits of 768.0
+constexpr int ZR_BASE = 0x44000000 + (224 << 14);  // CODES 1: D' of distance 0 for a query with P = 0
+constexpr int NEVER = 0x7f000000;         // a result that is never below a start value (rows past the end)
 // One tile = 32 * NB queries of a job (lane l: column l & 31 of each block of 32, half l >> 5 of
 // the k range) against the split's share of the train range, 32 rows at a time.  Software
 // pipeline over (32 train rows, query block) steps: the four MFMAs of the next step are issued
@@ -131,7 +167,7 @@ constexpr int GROUP_D_START = 0x43400000; // bits of 192.0 = the accumulators' s
 // loop away (one job per call): the loop costs registers (NB 8: 237 -> 252, still two waves per
 // SIMD; NB 4: 166 -> 190 and NB 2: 117 -> 140 would each lose a wave per SIMD), so only the
 // 256-query-tile kernel of the batched scan has it.
-template <int NB, bool RUNS>
+template <int NB, bool RUNS, int CODES>
 __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
                                              const Job* __restrict__ jobs, u32 j0, u32 j1, u32 q0, u32 lane,
                                              u32 split, u32 splits, u32 split_stride, uint2* __restrict__ scratch,
@@ -139,27 +175,44 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
   Job job = jobs[j0];
   const u32 c = lane & 31, h = lane >> 5;
 
+  constexpr int DSH = CODES ? 14 : 15;  // the distance's place in a result's bits
   u32 m88 = 0x88888888u, c22 = 0x11111111u;  // (the name is history: codes 0x1 / 0x9 = +-0.5)
+  u32 m44 = 0x44444444u, m22 = 0x22222222u, m11 = 0x11111111u;
   asm volatile("" : "+s"(m88), "+v"(c22));
+  if (CODES) asm volatile("" : "+s"(m44), "+s"(m22), "+s"(m11));
+  auto expand_train = [&](u32 w) { return CODES ? expand_train_zr(w, m88, c22, m44, m22, m11) : expand_bits_r(w, m88, c22); };
   i32x8 B[NB][4];
+  // D' of distance 0 for the block's query of this lane: CODES 0 the same for every query; CODES 1
+  // ZR_BASE - (P << 14), the P of four blocks packed into one register (they live through the whole scan)
+  u32 ppack[(NB + 3) / 4] = {};
+  auto zq = [&](int b) { return CODES ? ZR_BASE - (int)(((ppack[b >> 2] >> (8 * (b & 3))) & 255u) << 14) : GROUP_D_BASE; };
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     const u32 qi = min(q0 + b * 32 + c, job.nq - 1);
     const u32 colb = job.qlist_off != NO_QLIST ? qlist[job.qlist_off + qi] : qi;
     const u32x4 w = qbase[2 * (size_t)(job.q_off + colb) + h];
-    B[b][0] = expand_bits_r(~w.x, m88, c22);
-    B[b][1] = expand_bits_r(~w.y, m88, c22);
-    B[b][2] = expand_bits_r(~w.z, m88, c22);
-    B[b][3] = expand_bits_r(~w.w, m88, c22);
+    if (CODES) {
+      B[b][0] = expand_query_zr(w.x);
+      B[b][1] = expand_query_zr(w.y);
+      B[b][2] = expand_query_zr(w.z);
+      B[b][3] = expand_query_zr(w.w);
+      const int ph = __popc(w.x & 0x77777777u) + __popc(w.y & 0x77777777u) + __popc(w.z & 0x77777777u) + __popc(w.w & 0x77777777u);
+      ppack[b >> 2] |= (u32)(ph + __shfl_xor(ph, 32)) << (8 * (b & 3));
+    } else {
+      B[b][0] = expand_bits_r(~w.x, m88, c22);
+      B[b][1] = expand_bits_r(~w.y, m88, c22);
+      B[b][2] = expand_bits_r(~w.z, m88, c22);
+      B[b][3] = expand_bits_r(~w.w, m88, c22);
+    }
   }
-  const int init = d_lim >= 256u ? GROUP_D_256 : GROUP_D_BASE | (int)(d_lim << 15);
+  const int dl = (int)(min(d_lim, 256u) << DSH);  // start value of (best, second) above zq
   u32 j = j0;
   for (;;) {
   const u32 per = (job.nt + splits - 1) / splits;
   const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
   int best[NB], second[NB];
 #pragma unroll
-  for (int b = 0; b < NB; b++) best[b] = second[b] = init;
+  for (int b = 0; b < NB; b++) best[b] = second[b] = zq(b) + dl;
 
   if (t1 > t0) {
     // train rows: a wave-uniform base and a 32-bit byte offset per lane (row c of the step, half h),
@@ -171,16 +224,16 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
     // start values of the accumulators: 192.0 + i ulp, kept in registers for the whole scan
     f32x16 zero;
 #pragma unroll
-    for (int i = 0; i < 16; i++) zero[i] = __int_as_float(GROUP_D_START + i);
+    for (int i = 0; i < 16; i++) zero[i] = __int_as_float((CODES ? ZR_START : GROUP_D_START) + i);
     asm volatile("" : "+v"(zero));
     u32x4 w = row(off);
     u32x4 wn = row(off + 1024u);  // the step after: in flight while the current one is expanded
     off += 2048u;
     i32x8 A[4];
-    A[0] = expand_bits_r(w.x, m88, c22);
-    A[1] = expand_bits_r(w.y, m88, c22);
-    A[2] = expand_bits_r(w.z, m88, c22);
-    A[3] = expand_bits_r(w.w, m88, c22);
+    A[0] = expand_train(w.x);
+    A[1] = expand_train(w.y);
+    A[2] = expand_train(w.z);
+    A[3] = expand_train(w.w);
     f32x16 D = zero;
 #pragma unroll
     for (int m = 0; m < 4; m++) D = mfma_step(A[m], B[0][m], D);
@@ -194,16 +247,16 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
       const int m3 = min3i(x[9], x[10], x[11]), m4 = min3i(x[12], x[13], x[14]);
       return min(min3i(m0, m1, m2), min3i(m3, m4, x[15]));
     };
-    u32 step16 = 0, j = t0;  // step16 = 16 x the number of the 32-row step
-    for (; j + 32 <= t1; j += 32, step16 += 16) {
+    u32 step16 = 0, tr0 = t0;  // step16 = 16 x the number of the 32-row step, tr0 = its first train row
+    for (; tr0 + 32 <= t1; tr0 += 32, step16 += 16) {
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         f32x16 Dn = zero;
         auto expand_next = [&]() {  // the next step's train rows; the step after goes in flight
-          An[0] = expand_bits_r(wn.x, m88, c22);
-          An[1] = expand_bits_r(wn.y, m88, c22);
-          An[2] = expand_bits_r(wn.z, m88, c22);
-          An[3] = expand_bits_r(wn.w, m88, c22);
+          An[0] = expand_train(wn.x);
+          An[1] = expand_train(wn.y);
+          An[2] = expand_train(wn.z);
+          An[3] = expand_train(wn.w);
           wn = row(off);
           off += 1024u;
         };
@@ -241,16 +294,16 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
     }
     // The last, partial step of a range (once per scan, not pipelined): D holds its block 0, A
     // its operands; rows past the end are replaced by distance 256, which is never recorded.
-    if (j < t1) {
-      const u32 left = t1 - j - 4 * h;      // the lane's rows at offsets < left exist ...
-      const bool any_row = j + 4 * h < t1;  // ... if any does
+    if (tr0 < t1) {
+      const u32 left = t1 - tr0 - 4 * h;      // the lane's rows at offsets < left exist ...
+      const bool any_row = tr0 + 4 * h < t1;  // ... if any does
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         int x[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
           const u32 off = (u32)((i & 3) + 8 * (i >> 2));
-          x[i] = (any_row && off < left) ? __float_as_int(D[i]) : GROUP_D_256;
+          x[i] = (any_row && off < left) ? __float_as_int(D[i]) : NEVER;
         }
         const int m = group_min(x);
         second[b] = med3(best[b], m, second[b]);
@@ -269,15 +322,20 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
   // bits -> packed keys, the two halves of the wave (same queries, disjoint rows) merged exactly.
   u32 q0e = q0;
   asm volatile("" : "+s"(q0e));
+  if (CODES) {  // likewise the start values: unpacked again here, not carried through the scan
+#pragma unroll
+    for (int k = 0; k < (NB + 3) / 4; k++) asm volatile("" : "+v"(ppack[k]));
+  }
   uint2* out = scratch + (size_t)split * split_stride + job.out_off;
   const u32 sentinel = d_lim >= 256u ? KEY_INIT : ((d_lim << IDX_BITS) | t0);
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     const u32 bb = (u32)best[b], sb = (u32)second[b];
+    const int zb = zq(b), init = zb + dl;
     const u32 i = bb & 15u;
     const u32 row = t0 + 2 * ((bb >> 4) & 1023u) * 16 + 4 * h + (i & 3u) + 8 * (i >> 2);
-    const u32 kl = (int)bb < init ? ((((bb >> 15) & 255u) << IDX_BITS) | row) : sentinel;
-    const u32 sl = (int)(sb & ~32767u) < init ? (((sb >> 15) & 255u) << IDX_BITS) : sentinel;
+    const u32 kl = (int)bb < init ? (((((bb - (u32)zb) >> DSH) & 255u) << IDX_BITS) | row) : sentinel;
+    const u32 sl = (int)(sb & ~((1u << DSH) - 1u)) < init ? ((((sb - (u32)zb) >> DSH) & 255u) << IDX_BITS) : sentinel;
     const u32 ko = (u32)__shfl_xor((int)kl, 32), so = (u32)__shfl_xor((int)sl, 32);
     const u32 kb = min(kl, ko), ks = min(min(sl, so), max(kl, ko));
     const u32 qi = q0e + b * 32 + c;
@@ -300,14 +358,14 @@ __device__ __forceinline__ u32 mfma_scan_run(const u32x4* __restrict__ qbase, co
 // The grid counts queries in units of 64, a tile in blocks of 32: when the last block of a job's last
 // tile holds no query at all (2000 queries: the eighth 256-query tile has 208, six and a half blocks)
 // the tile runs with one block less -- 1/64 of the MFMA work of a 2000-query job.
-template <int NB, bool RUNS>
+template <int NB, bool RUNS, int CODES>
 __device__ __forceinline__ u32 mfma_scan_run_fit(const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase,
                                                  const Job* __restrict__ jobs, u32 j0, u32 j1, u32 nq, u32 q0, u32 lane,
                                                  u32 split, u32 splits, u32 split_stride, uint2* __restrict__ scratch,
                                                  const u32* __restrict__ qlist, u32 d_lim, const AcceptMask& acc) {
   if (NB > 1 && q0 + (NB - 1) * 32 >= nq)
-    return mfma_scan_run<(NB > 1 ? NB - 1 : 1), RUNS>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
-  return mfma_scan_run<NB, RUNS>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
+    return mfma_scan_run<(NB > 1 ? NB - 1 : 1), RUNS, CODES>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
+  return mfma_scan_run<NB, RUNS, CODES>(qbase, tbase, jobs, j0, j1, q0, lane, split, splits, split_stride, scratch, qlist, d_lim, acc);
 }
 
 // WAVES == 1: one-wave workgroups, the grid of scan_kernel_adaptive<*, 1, *>: tiles of 32 * NBMAX
@@ -316,7 +374,10 @@ __device__ __forceinline__ u32 mfma_scan_run_fit(const u32x4* __restrict__ qbase
 // NBMAX == 2 for one stereo pair and for the pruned backward pass, most of whose workgroups find
 // nothing to do.  Registers: 252 (NBMAX 8 with the job loop of mfma_scan_run, 237 without: two waves
 // per SIMD), 166 (4: three), 117 (2: four).
-template <int NBMAX, int WAVES = 1>
+#ifndef VSM_SCAN_CODES
+#define VSM_SCAN_CODES 0
+#endif
+template <int NBMAX, int WAVES = 1, int CODES = VSM_SCAN_CODES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
     u32 splits, u32 split_stride, uint2* __restrict__ scratch, const u32* __restrict__ qlist, u32 tiles_per_job,
@@ -350,17 +411,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2)))
     const u32 nq = jobs[j].nq;
     const u32 n64 = (nq + 63) >> 6, full = n64 / RMAX, rem = n64 & (RMAX - 1);
     if (t < full) {
-      return mfma_scan_run_fit<NBMAX, RUNS>(qbase, tbase, jobs, j, j1, nq, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+      return mfma_scan_run_fit<NBMAX, RUNS, CODES>(qbase, tbase, jobs, j, j1, nq, t * 64 * RMAX, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
     }
     u32 k = t - full, q0 = full * 64 * RMAX;
     if (RMAX > 2 && (rem & 2)) {
       if (k == 0)
-        return mfma_scan_run_fit<4, RUNS>(qbase, tbase, jobs, j, j1, nq, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+        return mfma_scan_run_fit<4, RUNS, CODES>(qbase, tbase, jobs, j, j1, nq, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
       k--;
       q0 += 128;
     }
     if ((rem & 1) && k == 0)
-      return mfma_scan_run_fit<2, RUNS>(qbase, tbase, jobs, j, j1, nq, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
+      return mfma_scan_run_fit<2, RUNS, CODES>(qbase, tbase, jobs, j, j1, nq, q0, lane, blockIdx.y, splits, split_stride, scratch, qlist, d_lim, acc);
     return j + 1;  // this job has no tile t
   };
   if (RUNS) {

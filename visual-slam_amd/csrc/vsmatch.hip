@@ -793,8 +793,11 @@ int vsm_match_pairs(vsm_ctx* c, const uint32_t* pairs, size_t n_pairs, int thres
 int vsm_db_upload_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint64_t* desc, const uint32_t* offsets, size_t n_img) {
   if (!ctxs || n_ctx == 0) return fail(VSM_ERR_INVALID, "no contexts");
   for (size_t k = 0; k < n_ctx; k++) VSM_TRY(check_ctx(ctxs[k]));
-  VSM_TRY(vsm_db_upload(ctxs[0], desc, offsets, n_img));  // validates everything, host -> first context
   vsm_ctx* c0 = ctxs[0];
+  // context 0 stays locked to the end: the other contexts copy out of ITS buffer, which a concurrent call on
+  // context 0 could otherwise free or regrow in between (the mutex is recursive: vsm_db_upload takes it again)
+  std::lock_guard<std::recursive_mutex> lk0(c0->mu);
+  VSM_TRY(vsm_db_upload(c0, desc, offsets, n_img));  // validates everything, host -> first context (synchronised)
   const size_t bytes = (size_t)offsets[n_img] * DESC_BYTES;
   for (size_t k = 1; k < n_ctx; k++) {
     vsm_ctx* c = ctxs[k];
@@ -805,14 +808,16 @@ int vsm_db_upload_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint64_t* desc
     c->img_off.clear();
     VSM_TRY(c->db_owned.reserve(std::max<size_t>(bytes, 256)));
     if (bytes) {
-      // device to device: xGMI between the GPUs of a node (the runtime stages through the host where
-      // two devices are not peers); from the host again if that fails
+      // device to device on the receiving context's stream: xGMI between the GPUs of a node (the runtime
+      // stages through the host where two devices are not peers); from the host again if that fails.
+      // set_db synchronises the stream before it reads the copy.
       hipError_t e = c->device == c0->device
-                         ? hipMemcpy(c->db_owned.p, c0->db_owned.p, bytes, hipMemcpyDeviceToDevice)
-                         : hipMemcpyPeer(c->db_owned.p, c->device, c0->db_owned.p, c0->device, bytes);
+                         ? hipMemcpyAsync(c->db_owned.p, c0->db_owned.p, bytes, hipMemcpyDeviceToDevice, c->stream)
+                         : hipMemcpyPeerAsync(c->db_owned.p, c->device, c0->db_owned.p, c0->device, bytes, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
       if (e != hipSuccess) {
         (void)hipGetLastError();
-        HIP_TRY(hipMemcpy(c->db_owned.p, desc, bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(c->db_owned.p, desc, bytes, hipMemcpyHostToDevice, c->stream));
       }
     }
     VSM_TRY(set_db(c, c->db_owned.p, offsets, n_img));
@@ -852,15 +857,27 @@ int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pa
   auto worker = [&](size_t k) {
     vsm_ctx* c = ctxs[k];
     Part& pt = parts[k];
-    // phase 1: this context's blocks k, k + n_ctx, ... as one batch on its GPU, lists stay in its HBM
-    for (size_t b = k; b < n_blocks; b += n_ctx) {
-      const size_t p0 = b * BLOCK, p1 = std::min(n_pairs, p0 + BLOCK);
-      pt.pairs.insert(pt.pairs.end(), pairs + 2 * p0, pairs + 2 * p1);
-    }
-    const size_t n_local = pt.pairs.size() / 2;
     std::lock_guard<std::recursive_mutex> lk(c->mu);  // held to the end: the lists live in the context's buffers
     DeviceGuard g(c->device);
+    // No exception leaves this function (it runs on a std::thread under an extern "C" entry point): a failed
+    // allocation becomes the part's error code, and the barrier below is reached either way.
+    auto guarded = [&](auto&& f) -> int {
+      try {
+        return f();
+      } catch (const std::bad_alloc&) {
+        return fail(VSM_ERR_NOMEM, "out of host memory");
+      } catch (const std::exception& e) {
+        return fail(VSM_ERR_INVALID, "%s", e.what());
+      }
+    };
+    size_t n_local = 0;
     auto run = [&]() -> int {
+      // phase 1: this context's blocks k, k + n_ctx, ... as one batch on its GPU, lists stay in its HBM
+      for (size_t b = k; b < n_blocks; b += n_ctx) {
+        const size_t p0 = b * BLOCK, p1 = std::min(n_pairs, p0 + BLOCK);
+        pt.pairs.insert(pt.pairs.end(), pairs + 2 * p0, pairs + 2 * p1);
+      }
+      n_local = pt.pairs.size() / 2;
       const size_t n_img = c->img_off.size() - 1;
       size_t bound = 0;  // the cross-check emits at most min(n1, n2) pairs per image pair
       for (size_t i = 0; i < n_local; i++) {
@@ -881,7 +898,7 @@ int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pa
       HIP_TRY(hipStreamSynchronize(c->stream));
       return rc;
     };
-    pt.rc = run();
+    pt.rc = guarded(run);
     if (pt.rc != VSM_OK) pt.err = g_err;
     // barrier; the last context to arrive lays out the merged list in canonical pair order
     {
@@ -924,7 +941,7 @@ int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pa
       HIP_TRY(hipStreamSynchronize(c->stream));
       return VSM_OK;
     };
-    const int rc2 = copy_out();
+    const int rc2 = guarded(copy_out);
     if (rc2 != VSM_OK) {
       pt.rc = rc2;
       pt.err = g_err;
@@ -935,7 +952,23 @@ int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pa
     worker(0);
   } else {
     std::vector<std::thread> th;
-    for (size_t k = 0; k < n_ctx; k++) th.emplace_back(worker, k);
+    try {
+      th.reserve(n_ctx);
+      for (size_t k = 0; k < n_ctx; k++) th.emplace_back(worker, k);
+    } catch (const std::exception& e) {
+      // a thread could not be started: the ones already running wait at the barrier for n_ctx arrivals --
+      // the missing workers arrive here, as failed parts, so that everybody leaves
+      std::unique_lock<std::mutex> bl(bm);
+      for (size_t k = th.size(); k < n_ctx; k++) {
+        parts[k].rc = VSM_ERR_NOMEM;
+        parts[k].err = std::string("could not start a host thread: ") + e.what();
+      }
+      arrived += n_ctx - th.size();
+      if (arrived == n_ctx) {
+        released = true;
+        bcv.notify_all();
+      }
+    }
     for (std::thread& t : th) t.join();
   }
   for (const Part& q : parts)
@@ -946,6 +979,23 @@ int vsm_match_pairs_multi(vsm_ctx* const* ctxs, size_t n_ctx, const uint32_t* pa
   return VSM_OK;
 }
 
+}  // extern "C"
+// Waits for the flag word a kernel raises in mapped host memory after its last write: a spin of at most ~200 us
+// (one stereo pair is ~30 us end to end), then the caller falls back to hipStreamSynchronize, which sleeps -- with
+// the reference's 16 TBB workers calling at once (src/sfm.cpp:1295) sixteen cores would otherwise spin for as long
+// as the GPU queues their work.  true: the flag was seen (acquire).
+static bool poll_flag(volatile u64* flag, u64 seq) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (u32 spin = 0;; spin++) {
+    if (*flag == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      return true;
+    }
+    __builtin_ia32_pause();
+    if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) return false;
+  }
+}
+extern "C" {
 int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2, size_t n2,
                    int threshold, double dist_2_best, int32_t* out_pairs, size_t cap_pairs,
                    size_t* out_count) {
@@ -976,6 +1026,11 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
   VSM_TRY(c->stage.reserve(up_bytes + 16));
   const bool mapped = c->pin_out.dev != nullptr;
   if (!mapped) VSM_TRY(c->w_out.reserve(down_bytes));
+  // The flag word starts from 0: pin_out is also written by other entry points of this context (the ORB kernels
+  // put moments there) and a fresh block may hold another context's sequence numbers -- a stale word equal to
+  // `seq` would let the host read the list before the emit kernel has run.  Nothing of this context is in
+  // flight here (every entry point that uses pin_out waits for its own work before it returns).
+  *(volatile u64*)((char*)c->pin_out.p + 16) = 0;
   char* h = (char*)c->pin_in.p;
   memcpy(h, d1, n1 * DESC_BYTES);
   memcpy(h + n1 * DESC_BYTES, d2, n2 * DESC_BYTES);
@@ -1010,15 +1065,7 @@ int vsm_match_pair(vsm_ctx* c, const uint64_t* d1, size_t n1, const uint64_t* d2
                      mapped ? (u64*)(d_down + 16) : (u64*)nullptr, seq);
   HIP_TRY(hipGetLastError());
   char* hd = (char*)c->pin_out.p;
-  bool seen = false;
-  if (mapped && !c->profiling) {
-    // poll the flag the emit kernel raises after its last write (~2 s, then fall back to the stream)
-    for (u32 spin = 0; spin < (1u << 28) && !seen; spin++) {
-      seen = *h_flag == seq;
-      if (!seen) __builtin_ia32_pause();
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
+  const bool seen = mapped && !c->profiling && poll_flag(h_flag, seq);
   if (!seen) {
     if (!mapped) HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, down_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1180,6 +1227,7 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   VSM_TRY(c->stage.reserve(up_bytes + 16));
   const bool mapped = c->pin_out.dev != nullptr;
   if (!mapped) VSM_TRY(c->w_out.reserve(down_bytes));
+  *(volatile u64*)((char*)c->pin_out.p + 16) = 0;  // the flag starts from 0 (see vsm_match_pair)
   char* h = (char*)c->pin_in.p;
   memcpy(h + o_kd, kp_desc, nk * DESC_BYTES);
   if (n_obs) memcpy(h + o_od, obs_desc, n_obs * DESC_BYTES);
@@ -1225,14 +1273,7 @@ int vsm_match_landmarks(vsm_ctx* c, const uint64_t* kp_desc, const double* kp_xy
   HIP_TRY(hipGetLastError());
   char* hd = (char*)c->pin_out.p;
   volatile u64* h_flag = (volatile u64*)(hd + 16);
-  bool seen = false;
-  if (mapped && !c->profiling) {
-    for (u32 spin = 0; spin < (1u << 28) && !seen; spin++) {
-      seen = *h_flag == seq;
-      if (!seen) __builtin_ia32_pause();
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-  }
+  const bool seen = mapped && !c->profiling && poll_flag(h_flag, seq);
   if (!seen) {
     if (!mapped) HIP_TRY(hipMemcpyAsync(hd, c->w_out.p, 64 + cap * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
