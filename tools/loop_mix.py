@@ -13,7 +13,7 @@ for i, l in enumerate(L):
         ops = [x.split()[0] for x in L[a:i + 1] if x.startswith('\t') and not x.strip().startswith(';')]
         c = Counter(ops)
         nm = sum(v for k, v in c.items() if k.startswith('v_mfma'))
-        if nm >= nmin and i - a < 600:
+        if nm >= nmin and i - a < 3000:
             valu = sum(v for k, v in c.items() if k.startswith('v_') and not k.startswith('v_mfma'))
             print(f"loop lines {a}-{i}: mfma {nm} valu {valu} ({valu / (nm / 4):.2f} per step)")
             print("  ", dict(c.most_common()))

@@ -12,6 +12,7 @@
 #include <vector>
 #ifdef VSM_PRODUCT  // -DVSM_PRODUCT: the shipped kernel only (csrc/mfma_scan.h), for tuning it
 #include "mfma_scan.h"
+#include "mfma16_scan.h"
 #else
 #include "history/mfma_scan_forms.h"
 #endif
@@ -269,7 +270,9 @@ int main(int argc, char** argv) {
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
-  const V vs[] = {{"shipped NB8", 24, 8}, {"zero-rich codes NB8", 64, 8}, {"shipped NB8", 24, 8}, {"zero-rich codes NB8", 64, 8},
+  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16x128, 192-query tiles", 74, 12}, {"16x16x128, 128-query tiles", 74, 8},
+                  {"16x16x128, 160-query tiles", 74, 10}, {"16x16x128, 224-query tiles", 74, 14},
+                  {"shipped NB8", 24, 8}, {"16x16x128, 192-query tiles", 74, 12}, {"zero-rich codes NB8", 64, 8},
                   {"shipped NB4", 24, 4}, {"zero-rich codes NB4", 64, 4}, {"shipped NB2", 24, 2}, {"zero-rich codes NB2", 64, 2},
                   {"NB8, 4-wave workgroups", 44, 8}, {"NB4, 4-wave workgroups", 44, 4},
                   {"EXPERIMENT: LDS-shared operands, 8 waves", 54, 8}, {"EXPERIMENT: LDS-shared operands, 4 waves", 54, 4},
@@ -280,7 +283,7 @@ int main(int argc, char** argv) {
 #endif
   for (const V& v : vs) {
     float tm = 1e30f;
-    const u32 tiles = adaptive_tiles(N, v.nb / 2), groups = (n_jobs + 7) / 8;
+    const u32 tiles = adaptive_tiles(N, v.fmt == 74 ? 4 : v.nb / 2), groups = (n_jobs + 7) / 8;
     for (int rep = 0; rep < 3; rep++) {
       CK(hipMemset(scr, 0xff, n_scr * sizeof(uint2)));
       CK(hipEventRecord(e0));
@@ -302,6 +305,15 @@ int main(int argc, char** argv) {
 #define ARGS4 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, nullptr, 0u, d_lim
         if (v.nb == 8) mfma_scan_kernel<8, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
         else mfma_scan_kernel<4, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
+      } else
+      if (v.fmt == 74) {
+        const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);
+        const dim3 g16(groups * 8 * t16);
+#define ARGS16 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, scr, t16, d_lim
+        if (v.nb == 12) mfma16_scan_kernel<12><<<g16, blk>>>(ARGS16);
+        else if (v.nb == 8) mfma16_scan_kernel<8><<<g16, blk>>>(ARGS16);
+        else if (v.nb == 10) mfma16_scan_kernel<10><<<g16, blk>>>(ARGS16);
+        else mfma16_scan_kernel<14><<<g16, blk>>>(ARGS16);
       } else
       if (v.fmt == 64) {
         if (v.nb == 8) mfma_scan_kernel<8, 1, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
@@ -327,7 +339,7 @@ int main(int argc, char** argv) {
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
     }
-    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64) {
+    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64 || v.fmt == 74) {
       CK(hipEventRecord(e0));
       refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr);
       CK(hipEventRecord(e1));

@@ -302,12 +302,14 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
 //   bits 8-15   number of train splits
 //   bit 16      no pruning of the backward pass
 //   bit 17      popcount scan with integer keys (FILL 2) instead of float keys (FILL 8)
+//   bit 18      the OTHER operand codes of the matrix-core scan (mfma_scan.h CODES): +-0.5 codes where the
+//               library uses the shift-free zero-rich ones (128- and 64-query tiles) and vice versa (256)
 //   bits 20-23  consecutive jobs per wave of the matrix-core batched scan (0 = the library's choice)
 //   bit 25      popcount scan everywhere (the formulation of BASELINE.json's north_star)
 //   bit 26      popcount scan in the pruned backward pass only
 //   bit 27      popcount scan for the latency shape only
 //   bits 28-30  adaptive full-tile size: 4 / 2 / 1 = 256 / 128 / 64 queries
-constexpr int KNOB_NO_PRUNE = 0x10000, KNOB_INT_KEYS = 0x20000, KNOB_POPCOUNT = 0x2000000,
+constexpr int KNOB_NO_PRUNE = 0x10000, KNOB_INT_KEYS = 0x20000, KNOB_FLIP_CODES = 0x40000, KNOB_POPCOUNT = 0x2000000,
               KNOB_POPCOUNT_BACKWARD = 0x4000000, KNOB_POPCOUNT_LATENCY = 0x8000000;
 
 // Tile form and train splits.  Large batches: adaptive tiles (256 queries or fewer), one-wave
@@ -403,9 +405,19 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   // popcount scans: float keys with the skip test (FILL 8) unless a split scans more than 32768
   // rows or the knob asks for integer keys (FILL 2)
   const bool fill8 = sh.fkey && !(c->variant & KNOB_INT_KEYS);
-#define VSM_LAUNCH_M(NN, WW)                                                                                       \
-  hipLaunchKernelGGL((mfma_scan_kernel<NN, WW>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
+  // Operand codes (mfma_scan.h): the shift-free zero-rich train codes for the 128- and 64-query tiles (16 instead of
+  // 28 expansion instructions per 32 train rows, spread over 4 or 2 query blocks: +2 % and +5.7 % on the same box,
+  // profiles/r03/scan_codes_and_shapes.txt), the +-0.5 codes for the 256-query tiles (no gain there: the expansion is
+  // spread over 8 blocks, and the loop over a run of jobs leaves no register for the queries' constants)
+  const bool flip = (c->variant & KNOB_FLIP_CODES) != 0;
+#define VSM_LAUNCH_MC(NN, WW, CC)                                                                                      \
+  hipLaunchKernelGGL((mfma_scan_kernel<NN, WW, CC>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
                      split_stride, d_scratch, d_qlist, grouped, d_lim, acc, sh.adaptive ? sh.jobs_per_wave : 1u)
+#define VSM_LAUNCH_M(NN, WW)                                  \
+  do {                                                        \
+    if ((NN == 8) == flip) VSM_LAUNCH_MC(NN, WW, 1);          \
+    else VSM_LAUNCH_MC(NN, WW, 0);                            \
+  } while (0)
 #define VSM_LAUNCH_A(FF, RR)                                                                                        \
   hipLaunchKernelGGL((scan_kernel_adaptive<FF, RR>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
                      split_stride, d_scratch, d_qlist, grouped)
@@ -431,6 +443,7 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #undef VSM_LAUNCH
 #undef VSM_LAUNCH_A
 #undef VSM_LAUNCH_M
+#undef VSM_LAUNCH_MC
   HIP_TRY(hipGetLastError());
   if (timed) HIP_TRY(hipEventRecord(e1, c->stream));
   c->scan_launches[kind]++;
