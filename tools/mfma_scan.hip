@@ -42,10 +42,16 @@ __global__ void fill_db(u32* p, u32 n_img, u32 N, u32 plant) {
 
 // The group form stores an upper bound of the second best distance; the library's consumers make
 // it exact with refine_second (vsmatch_kernels.h) where it matters -- here for every entry.
-__global__ void refine_all(const u32x4* db, const Job* jobs, uint2* scr) {
+__global__ void refine_all(const u32x4* db, const Job* jobs, uint2* scr, int v2 = 0) {
   const Job job = jobs[blockIdx.x];
   for (u32 q = threadIdx.x; q < job.nq; q += blockDim.x) {
     const uint2 v = scr[job.out_off + q];
+#ifdef VSM_PRODUCT
+    if (v2) {
+      scr[job.out_off + q].y = refine_second_v3(db + 2 * (size_t)(job.q_off + q), db + 2 * (size_t)job.t_off, job.nt, v) << IDX_BITS;
+      continue;
+    }
+#endif
     const u32 s = refine_second(db + 2 * (size_t)(job.q_off + q), db + 2 * (size_t)job.t_off, job.nt, job.nt, v);
     scr[job.out_off + q].y = s << IDX_BITS;
   }
@@ -270,7 +276,9 @@ int main(int argc, char** argv) {
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
-  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16x128, 192-query tiles", 74, 12}, {"16x16x128, 128-query tiles", 74, 8},
+  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12}, {"16x16 v3, 208-query tiles", 84, 13},
+                  {"shipped NB8", 24, 8}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12},
+                  {"16x16x128, 192-query tiles", 74, 12}, {"16x16x128, 128-query tiles", 74, 8},
                   {"16x16x128, 160-query tiles", 74, 10}, {"16x16x128, 224-query tiles", 74, 14},
                   {"shipped NB8", 24, 8}, {"16x16x128, 192-query tiles", 74, 12}, {"zero-rich codes NB8", 64, 8},
                   {"shipped NB4", 24, 4}, {"zero-rich codes NB4", 64, 4}, {"shipped NB2", 24, 2}, {"zero-rich codes NB2", 64, 2},
@@ -306,6 +314,14 @@ int main(int argc, char** argv) {
         if (v.nb == 8) mfma_scan_kernel<8, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
         else mfma_scan_kernel<4, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
       } else
+      if (v.fmt == 84) {
+        const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);
+        const dim3 g16(groups * 8 * t16);
+#define ARGS16V2 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, scr, t16, d_lim
+        if (v.nb == 12) mfma16v3_scan_kernel<12><<<g16, blk>>>(ARGS16V2);
+        else if (v.nb == 13) mfma16v3_scan_kernel<13><<<g16, blk>>>(ARGS16V2);
+        else mfma16v3_scan_kernel<14><<<g16, blk>>>(ARGS16V2);
+      } else
       if (v.fmt == 74) {
         const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);
         const dim3 g16(groups * 8 * t16);
@@ -339,9 +355,9 @@ int main(int argc, char** argv) {
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
     }
-    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64 || v.fmt == 74) {
+    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64 || v.fmt == 74 || v.fmt == 84) {
       CK(hipEventRecord(e0));
-      refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr);
+      refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr, v.fmt == 84);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float t; CK(hipEventElapsedTime(&t, e0, e1));
