@@ -19,7 +19,6 @@
 
 namespace vsm {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma16_step(const i32x8 a, const i32x8 b, const f32x4 c) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0);

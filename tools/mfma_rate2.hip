@@ -27,6 +27,15 @@ __device__ __forceinline__ void load_codes(const unsigned* src, i32x8 (&a)[4], i
       } else if (DATA == 1) {
         a[m][s] = s == 0 ? (int)((wa & 0x88888888u) | 0x11111111u) : (int)(wa & (0x88888888u >> s));
         b[m][s] = (int)((wb & 0x88888888u) | (s == 0 ? 0x22222222u : s == 1 ? 0x11111111u : s == 2 ? 0x22222222u : 0x44444444u));
+      } else if (DATA == 3) {  // both sides: a code is zero or one magnitude (0.5 / 1.0 / 2.0), half of them zero
+        a[m][s] = (int)(wa & (0x11111111u << (s % 3)));
+        b[m][s] = (int)(wb & (0x11111111u << ((s + 1) % 3)));
+      } else if (DATA == 4) {  // train zero or one magnitude, query +-0.5
+        a[m][s] = (int)(wa & (0x11111111u << (s % 3)));
+        b[m][s] = (int)((wb & 0x88888888u) | 0x11111111u);
+      } else if (DATA == 5) {  // both sides zero or 1.0, a quarter of the bits set (sparser descriptors)
+        a[m][s] = (int)(wa & (wa >> 4 | wa << 28) & 0x22222222u);
+        b[m][s] = (int)(wb & (wb >> 4 | wb << 28) & 0x22222222u);
       }
     }
   }
@@ -135,6 +144,11 @@ int main() {
     run<32, 0, 2>("32x32x64  +-0.5, pairs share B", src, out, st);
     run<32, 1>("32x32x64  zero-rich train codes", src, out, st);
     run<16, 1>("16x16x128 zero-rich train codes", src, out, st);
+    run<32, 3>("32x32x64  0 / x codes both sides", src, out, st);
+    run<16, 3>("16x16x128 0 / x codes both sides", src, out, st);
+    run<32, 4>("32x32x64  0 / x train, +-0.5 query", src, out, st);
+    run<16, 4>("16x16x128 0 / x train, +-0.5 query", src, out, st);
+    run<32, 5>("32x32x64  0 / 1 both, quarter set", src, out, st);
     run<32, 2>("32x32x64  zeros", src, out, st);
     run<16, 2>("16x16x128 zeros", src, out, st);
   }
