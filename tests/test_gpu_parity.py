@@ -53,11 +53,13 @@ def test_pair_matches_recorded_reference(m, name):
 # 26 in the pruned backward pass, 27 in the latency shape; bits 28-30 adaptive full-tile size.
 POPCOUNT, INT_KEYS, NO_PRUNE, POP_BACK, POP_LAT = 0x2000000, 0x20000, 0x10000, 0x4000000, 0x8000000
 TILE256, TILE128, TILE64 = 0x40000000, 0x20000000, 0x10000000
+M16, M16_OFF = 0x1000000, 0x80000  # bit 24 / 19: always / never the 16x16x128 forward scan (mfma16_scan.h) where its shape allows it
 FLIP = 0x40000  # bit 18: the other operand codes of the matrix-core scan (+-0.5 <-> shift-free zero-rich, mfma_scan.h CODES)
 RUN2, RUN3, RUN4, RUN8 = 0x200000, 0x300000, 0x400000, 0x800000  # consecutive jobs per wave of the batched matrix-core scan
 
 
 @pytest.mark.parametrize("variant", [1, 4, 8, 0x0301, 0x0308, 0x1708, 0x4008, TILE256 | 8, TILE128 | 8, TILE64 | 8, TILE128 | 0x0208,
+                                     M16 | 8, M16_OFF | 8, M16 | NO_PRUNE | 8,
                                      FLIP | 1, FLIP | 8, FLIP | 0x0301, FLIP | 0x0308, FLIP | TILE256 | 8, FLIP | TILE128 | 8, FLIP | TILE64 | 8,
                                      POPCOUNT | 1, POPCOUNT | 4, POPCOUNT | 8, POPCOUNT | 0x0308, POPCOUNT | 0x0301,
                                      POPCOUNT | INT_KEYS | 1, POPCOUNT | INT_KEYS | 4, POPCOUNT | INT_KEYS | 8,
@@ -84,7 +86,7 @@ def test_accept_limit_of_the_matrix_core_scan(m, thr, ratio):
     """The matrix-core scan starts (best, second) at the smallest distance the accept test
     cannot tell from anything larger (accept_limit, vsmatch.hip); whatever threshold and ratio
     that limit is derived from, the list is the oracle's."""
-    for variant in (8, TILE64 | 8, 0x0308, 1, 0x0301, FLIP | 8, FLIP | TILE64 | 8, FLIP | 1):
+    for variant in (8, TILE64 | 8, 0x0308, 1, 0x0301, FLIP | 8, FLIP | TILE64 | 8, FLIP | 1, M16 | 8):
         m.set_variant(variant)
         try:
             for (n1, n2, seed) in [(300, 777, 1), (1023, 1025, 2), (64, 33, 3), (5, 2000, 4)]:
@@ -106,7 +108,7 @@ def _real_like_database(n_img, n_desc, seed):
     return db, (np.arange(n_img + 1) * n_desc).astype(np.uint32)
 
 
-@pytest.mark.parametrize("variant", [8, TILE64 | 8, TILE128 | 8, 0x0308, 1, 0x0501, POPCOUNT | 8, FLIP | 8, FLIP | TILE128 | 8, FLIP | 1])
+@pytest.mark.parametrize("variant", [8, TILE64 | 8, TILE128 | 8, 0x0308, 1, 0x0501, POPCOUNT | 8, FLIP | 8, FLIP | TILE128 | 8, FLIP | 1, M16 | 8])
 def test_real_descriptors_every_tail_length(m, variant):
     """Real ORB descriptors (many near neighbours, ties and second bests right next to the best)
     at train sizes around the 32-row step of the matrix-core scan -- the partial last step is
@@ -166,7 +168,7 @@ def test_second_best_next_to_the_best(m, gap):
     db = np.concatenate([q, t])
     pairs = np.array([[0, 1], [1, 0]] * 1100, np.uint32)  # enough jobs for the adaptive regime
     for variant in (0, 1, 8, TILE64 | 8, 0x0308, 0x0301, NO_PRUNE | 8, POPCOUNT | 8, RUN3 | TILE256 | 8, RUN8 | NO_PRUNE | TILE256 | 8,
-                    FLIP, FLIP | 1, FLIP | 8, FLIP | TILE64 | 8, FLIP | RUN3 | TILE256 | 8):
+                    FLIP, FLIP | 1, FLIP | 8, FLIP | TILE64 | 8, FLIP | RUN3 | TILE256 | 8, M16, M16 | 8, M16 | NO_PRUNE | 8, M16_OFF):
         m.set_variant(variant)
         try:
             assert np.array_equal(m.match(q, t, 70, 1.2), want), (hex(variant), gap)
@@ -238,7 +240,7 @@ def test_real_like_database_batched():
         want = [binding.port().match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2) for i, j in pairs.tolist()]
         assert sum(len(w) for w in want) > 10000
         for variant in (0, NO_PRUNE, POPCOUNT, POP_BACK, TILE64, 0x0200, 1, RUN2 | TILE256, RUN3 | TILE256, RUN8 | TILE256, RUN4 | NO_PRUNE | TILE256,
-                        FLIP, FLIP | TILE64, FLIP | RUN4 | TILE256):
+                        FLIP, FLIP | TILE64, FLIP | RUN4 | TILE256, M16, M16_OFF, M16 | NO_PRUNE):
             mm.set_variant(variant)
             offs, out = mm.match_pairs(pairs, 70, 1.2)
             for k, w in enumerate(want):
@@ -273,7 +275,7 @@ def test_batched_pruned_path_under_many_accept_tests(thr, ratio):
 
 
 def test_nn2_vs_oracle(m):
-    for variant in (0, 8, 1, TILE64 | 8, TILE128 | 8, POPCOUNT | 8, POPCOUNT | INT_KEYS, POP_LAT | 1, FLIP | 8, FLIP | TILE64 | 8, FLIP | 1):
+    for variant in (0, 8, 1, TILE64 | 8, TILE128 | 8, POPCOUNT | 8, POPCOUNT | INT_KEYS, POP_LAT | 1, FLIP | 8, FLIP | TILE64 | 8, FLIP | 1, M16 | 8):
         m.set_variant(variant)
         try:
             for (nq, nt, seed) in [(1, 1, 1), (5, 9, 2), (64, 64, 3), (257, 1000, 4), (1000, 257, 5), (777, 3001, 6),

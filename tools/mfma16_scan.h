@@ -1,4 +1,5 @@
-// tools/mfma16_scan.h -- EXPERIMENT (round 3): the scan of csrc/mfma_scan.h on v_mfma_f32_16x16x128_f8f6f4.
+// tools/mfma16_scan.h -- EXPERIMENTS (round 3) behind csrc/mfma16_scan.h: the scan of csrc/mfma_scan.h on
+// v_mfma_f32_16x16x128_f8f6f4, first form (v1: groups of its own geometry) and v3 (32-row units, 32-row groups).
 //
 // Why: the bare instruction on random codes sustains 17.0-18.3 T comparisons/s on the whole chip at 2.15-2.35 GHz where
 // the 32x32x64 shape holds 14.4-16.7 T at 1.83-2.14 GHz (tools/mfma_rate2.hip, tools/valu_beside_mfma.hip: the chip is
@@ -14,19 +15,15 @@
 // eight v_min3, med3 / or / min).  The four lanes of a query are merged at the end.
 // Codes: the shift-free zero-rich ones of csrc/mfma_scan.h (CODES 1).
 #pragma once
-#include <type_traits>
-#include "mfma_scan.h"
+#include "../visual-slam_amd/csrc/mfma16_scan.h"  // the product kernel (csrc): typedefs, mfma16_step
 
 namespace vsm {
 
 
-__device__ __forceinline__ f32x4 mfma16_step(const i32x8 a, const i32x8 b, const f32x4 c) {
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0);
-}
 
 // One tile = 16 * NBQ queries of a job against its whole train range (unsplit).
 template <int NBQ>
-__device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes, const char* __restrict__ tbytes, const Job job,
+__device__ __forceinline__ void mfma16v1_scan_tile(const char* __restrict__ qbytes, const char* __restrict__ tbytes, const Job job,
                                                  u32 q0, u32 lane, uint2* __restrict__ scratch, u32 d_lim) {
   const u32 c = lane & 15, g = lane >> 4;
   u32 m88 = 0x88888888u, c11 = 0x11111111u, m44 = 0x44444444u, m22 = 0x22222222u, m11 = 0x11111111u;
@@ -183,7 +180,7 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
 }
 
 template <int NBQ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mfma16_scan_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mfma16v1_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
     uint2* __restrict__ scratch, u32 tiles_per_job, u32 d_lim) {
   const u32 lane = threadIdx.x & 63;
@@ -194,7 +191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mf
   const Job job = jobs[j];
   const u32 q0 = t * 16 * NBQ;
   if (q0 >= job.nq) return;
-  mfma16_scan_tile<NBQ>((const char*)qbase, (const char*)tbase, job, q0, lane, scratch, d_lim);
+  mfma16v1_scan_tile<NBQ>((const char*)qbase, (const char*)tbase, job, q0, lane, scratch, d_lim);
 }
 
 }  // namespace vsm
@@ -216,7 +213,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mf
 // SIMD share the 256 registers of a wave with the VGPRs, it spilled.)
 namespace vsm {
 
-typedef int i32x2v __attribute__((ext_vector_type(2)));
 
 template <int NBQ>
 __device__ __forceinline__ void mfma16v3_scan_tile(const char* __restrict__ qbytes, const char* __restrict__ tbytes, const Job job,

@@ -276,7 +276,7 @@ int main(int argc, char** argv) {
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
-  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12}, {"16x16 v3, 208-query tiles", 84, 13},
+  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16 product", 104, 14}, {"shipped NB8", 24, 8}, {"16x16 product", 104, 14}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12}, {"16x16 v3, 208-query tiles", 84, 13},
                   {"shipped NB8", 24, 8}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12},
                   {"16x16x128, 192-query tiles", 74, 12}, {"16x16x128, 128-query tiles", 74, 8},
                   {"16x16x128, 160-query tiles", 74, 10}, {"16x16x128, 224-query tiles", 74, 14},
@@ -314,6 +314,10 @@ int main(int argc, char** argv) {
         if (v.nb == 8) mfma_scan_kernel<8, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
         else mfma_scan_kernel<4, 4, 0><<<g4, b4>>>(ARGS4, AcceptMask{nullptr, 0, nullptr}, 1u);
       } else
+      if (v.fmt == 104) {
+        const u32 t16 = mfma16_tiles(N);
+        mfma16_scan_kernel<<<dim3(groups * 8 * t16), blk>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, scr, t16, d_lim, AcceptMask{nullptr, 0, nullptr});
+      } else
       if (v.fmt == 84) {
         const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);
         const dim3 g16(groups * 8 * t16);
@@ -326,10 +330,10 @@ int main(int argc, char** argv) {
         const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);
         const dim3 g16(groups * 8 * t16);
 #define ARGS16 (const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, scr, t16, d_lim
-        if (v.nb == 12) mfma16_scan_kernel<12><<<g16, blk>>>(ARGS16);
-        else if (v.nb == 8) mfma16_scan_kernel<8><<<g16, blk>>>(ARGS16);
-        else if (v.nb == 10) mfma16_scan_kernel<10><<<g16, blk>>>(ARGS16);
-        else mfma16_scan_kernel<14><<<g16, blk>>>(ARGS16);
+        if (v.nb == 12) mfma16v1_scan_kernel<12><<<g16, blk>>>(ARGS16);
+        else if (v.nb == 8) mfma16v1_scan_kernel<8><<<g16, blk>>>(ARGS16);
+        else if (v.nb == 10) mfma16v1_scan_kernel<10><<<g16, blk>>>(ARGS16);
+        else mfma16v1_scan_kernel<14><<<g16, blk>>>(ARGS16);
       } else
       if (v.fmt == 64) {
         if (v.nb == 8) mfma_scan_kernel<8, 1, 1><<<g, blk>>>(ARGS, AcceptMask{nullptr, 0, nullptr}, 1u);
@@ -355,7 +359,7 @@ int main(int argc, char** argv) {
       float t; CK(hipEventElapsedTime(&t, e0, e1));
       tm = std::min(tm, t);
     }
-    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64 || v.fmt == 74 || v.fmt == 84) {
+    if (v.fmt == 24 || v.fmt == 44 || v.fmt == 54 || v.fmt == 64 || v.fmt == 74 || v.fmt == 84 || v.fmt == 104) {
       CK(hipEventRecord(e0));
       refine_all<<<n_jobs, 256>>>((const u32x4*)db, d_jobs, scr, v.fmt == 84);
       CK(hipEventRecord(e1));

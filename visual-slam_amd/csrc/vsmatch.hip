@@ -5,6 +5,7 @@
 // entry point needs a HIP device and fails with VSM_ERR_HIP otherwise.
 #include "vsmatch_kernels.h"
 #include "mfma_scan.h"
+#include "mfma16_scan.h"
 #include "landmark_kernels.h"
 #include "orb_kernels.h"
 #include "gftt_kernels.h"
@@ -135,6 +136,44 @@ constexpr u32 LONG_SCAN_WAVES = 98304;              // long scans are split unti
 
 }  // namespace
 
+// The 16x16x128 forward scan (mfma16_scan.h) on a set of images: tiles per image and an estimate of its time against
+// the 32x32x64 scan's, both of the form  (padded queries, weighted by tile size) x (padded train rows + a fixed cost per
+// tile and block in rows).  Fitted to tools/mfma_scan.hip on one box (profiles/r03/scan16_product_by_size.txt): per
+// padded comparison the 16x16 scan takes 0.867 of the time, its fixed cost is 320 rows per block against 115 (two
+// merges of four lanes per result, no loop over a run of jobs, the tail behind the pipelined loop) -- it wins from
+// ~1200 train rows per image up: + 5 % at 2000 x 2000, + 10 % at 1333 (where the 32x32 tiling ends in a 64-query tile),
+// - 15 % at 500.
+struct Mfma16Stats {
+  u32 max_tiles = 0;
+  bool uniform = false;  // every image has exactly max_tiles tiles
+  bool prefer = false;
+};
+struct Mfma16Cost {
+  double q16 = 0, q32 = 0, t = 0;
+  size_t n = 0;
+  u32 max_tiles = 0, min_tiles = 0xffffffffu;
+  void add(u32 nd) {
+    // a tile of nb blocks: 11.6 VALU instructions per block and superstep + 32 for the expansion of the train rows,
+    // relative to the 14-block tile
+    const Mfma16Tiling tg = mfma16_tiling(nd);
+    q16 += 16 * (tg.big_tiles * (11.6 * (tg.small + 2) + 32) + (tg.tiles - tg.big_tiles) * (11.6 * tg.small + 32)) / (11.6 + 32 / 14.0);
+    // 32x32: full tiles of 256 queries, remainder tiles of 128 (- 3 %) and 64 (- 11 %), the last block left out when empty
+    const u32 n64 = (nd + 63) >> 6, full = n64 / 4, rem = n64 & 3;
+    q32 += full * 256.0 + ((rem & 2) ? 128 * 1.03 : 0.0) + ((rem & 1) ? 64 * 1.12 : 0.0) - (nd && ((nd - 1) & 63) < 32 ? 32.0 : 0.0);
+    t += (nd + 31) / 32 * 32;
+    n++;
+    max_tiles = std::max(max_tiles, tg.tiles);
+    min_tiles = std::min(min_tiles, tg.tiles);
+  }
+  Mfma16Stats stats() const {
+    Mfma16Stats s;
+    s.max_tiles = max_tiles;
+    s.uniform = n > 0 && min_tiles == max_tiles;
+    s.prefer = n > 0 && 0.867 * q16 * (t + 320.0 * n) < 0.99 * q32 * (t + 115.0 * n);
+    return s;
+  }
+};
+
 struct vsm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -151,6 +190,7 @@ struct vsm_ctx {
   u32 max_tiles[4] = {0, 0, 0, 0};
   bool uniform_tiles[4] = {false, false, false, false};
   double avg_tiles[4] = {0, 0, 0, 0};
+  Mfma16Stats m16;  // the same for the 224-query tiles of the 16x16x128 scan, and whether it pays on this database
   // work buffers
   DevBuf stage, scratch, jobs, counts, misc, qlist, flist, accmask, lut, w_pairs, w_offsets, w_out;
   DevBuf image, gftt;  // device image of the ORB/detection entry points; detector work buffers
@@ -284,6 +324,7 @@ struct ScanShape {
   bool fkey;      // a split scans <= FKEY_MAX_SET rows: float keys (popcount) / 10-bit step tags (matrix cores)
   bool mfma;      // matrix-core scan (mfma_scan.h); else the popcount scan (experiment knob only)
   u32 jobs_per_wave = 1;  // matrix-core adaptive scan: consecutive jobs a wave runs over (mfma_scan_run)
+  bool mfma16 = false;    // scans without a query list go through the 16x16x128 kernel (mfma16_scan.h); tiles, uniform: its own
 };
 
 // Most tiles the adaptive kernels can need for a job of at most max_nq queries (the tile
@@ -309,6 +350,8 @@ u32 adaptive_tiles_bound(u32 max_nq, u32 rmax) {
 //   bit 26      popcount scan in the pruned backward pass only
 //   bit 27      popcount scan for the latency shape only
 //   bits 28-30  adaptive full-tile size: 4 / 2 / 1 = 256 / 128 / 64 queries
+//   bit 19 / 24 never / always the 16x16x128 forward scan where its shape allows it (else: the estimate of Mfma16Cost)
+constexpr int KNOB_MFMA16_OFF = 0x80000, KNOB_MFMA16_ON = 0x1000000;
 constexpr int KNOB_NO_PRUNE = 0x10000, KNOB_INT_KEYS = 0x20000, KNOB_FLIP_CODES = 0x40000, KNOB_POPCOUNT = 0x2000000,
               KNOB_POPCOUNT_BACKWARD = 0x4000000, KNOB_POPCOUNT_LATENCY = 0x8000000;
 
@@ -317,7 +360,7 @@ constexpr int KNOB_NO_PRUNE = 0x10000, KNOB_INT_KEYS = 0x20000, KNOB_FLIP_CODES 
 // 64-query tiles and the train range split over grid.y so that all 256 CUs work.
 ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u32* exact_max_tiles = nullptr,
                        const bool* uniform_tiles = nullptr, const double* avg_tiles = nullptr,
-                       u64 jobs_per_launch = 0) {
+                       u64 jobs_per_launch = 0, const Mfma16Stats* m16 = nullptr) {
   ScanShape s;
   const int vr = variant & 0xff, vs = (variant >> 8) & 0xff;
   // adaptive tiles when 256-query tiles still leave enough waves to fill the chip (counting the
@@ -372,6 +415,22 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
     while (s.jobs_per_wave < 4 && w / (2 * s.jobs_per_wave) >= 32768) s.jobs_per_wave *= 2;
     const int fj = (variant >> 20) & 0xf;  // knob bits 20-23: forced
     if (fj) s.jobs_per_wave = (u32)fj;
+    // the 16x16x128 kernel instead (batched forward scans: unsplit, 256-query tiles, step tags of 10 bits)
+    Mfma16Stats st;
+    if (m16) {
+      st = *m16;
+    } else {
+      Mfma16Cost cost;
+      cost.add(max_nq);
+      st = cost.stats();
+      st.uniform = false;
+    }
+    s.mfma16 = (st.prefer || (variant & KNOB_MFMA16_ON)) && !(variant & KNOB_MFMA16_OFF) && st.max_tiles > 0;
+    if (s.mfma16) {
+      s.tiles = st.max_tiles;
+      s.uniform = st.uniform;
+      s.jobs_per_wave = 1;
+    }
   }
   return s;
 }
@@ -385,6 +444,7 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   if (n_jobs == 0) return VSM_OK;
   u64 blocks = n_jobs * sh.wgs_per_job;
   dim3 block(256);
+  const bool m16 = sh.mfma16 && !d_qlist;
   if (sh.adaptive) {
     const u64 groups = sh.mfma ? (n_jobs + sh.jobs_per_wave - 1) / sh.jobs_per_wave : n_jobs;  // mfma_scan_run
     blocks = (sh.uniform ? (groups + 7) / 8 * 8 : groups) * sh.tiles;
@@ -424,7 +484,9 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #define VSM_LAUNCH(RR, FF)                                                                                     \
   hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
                      split_stride, d_scratch, d_qlist)
-  if (sh.adaptive && sh.mfma) {  // shipped: FP4 matrix-core scan, 32 * NB queries per wave
+  if (m16) {  // FP4 matrix-core scan on the 16x16x128 shape, 224 queries per wave
+    hipLaunchKernelGGL(mfma16_scan_kernel, grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, d_scratch, grouped, d_lim, acc);
+  } else if (sh.adaptive && sh.mfma) {  // FP4 matrix-core scan on the 32x32x64 shape, 32 * NB queries per wave
     if (sh.rmax == 4) VSM_LAUNCH_M(8, 1);
     else if (sh.rmax == 2) VSM_LAUNCH_M(4, 1);
     else VSM_LAUNCH_M(2, 1);
@@ -476,7 +538,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   const bool own_db = d_desc == c->db;
   const ScanShape sh = choose_shape(2 * (u64)n_pairs, max_n, max_n, c->variant, own_db ? c->max_tiles : nullptr,
                                     own_db ? c->uniform_tiles : nullptr, own_db ? c->avg_tiles : nullptr,
-                                    std::min<u64>(n_pairs, 32768));  // forward jobs of one chunk
+                                    std::min<u64>(n_pairs, 32768),  // forward jobs of one chunk
+                                    own_db ? &c->m16 : nullptr);
   // chunk so that scratch (8 B per query per split, both directions) fits the budget
   const u64 per_pair = (u64)2 * stride * sizeof(uint2) * sh.splits;
   u64 chunk = std::max<u64>(1, SCRATCH_BUDGET / per_pair);
@@ -602,8 +665,10 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
   VSM_TRY(check_offsets(offsets, n_img));
   u32 max_n = 0, max_tiles[4] = {0, 0, 0, 0}, min_tiles[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
   double sum_tiles[4] = {0, 0, 0, 0};
+  Mfma16Cost cost16;
   for (size_t i = 0; i < n_img; i++) {
     max_n = std::max(max_n, offsets[i + 1] - offsets[i]);
+    cost16.add(offsets[i + 1] - offsets[i]);
     for (int ri = 0; ri < 4; ri++) {
       const u32 tl = adaptive_tiles(offsets[i + 1] - offsets[i], 8u >> ri);
       max_tiles[ri] = std::max(max_tiles[ri], tl);
@@ -622,6 +687,7 @@ int set_db(vsm_ctx* c, const void* d_desc, const uint32_t* offsets, size_t n_img
     c->uniform_tiles[ri] = n_img > 0 && min_tiles[ri] == max_tiles[ri];
     c->avg_tiles[ri] = n_img ? sum_tiles[ri] / (double)n_img : 0.0;
   }
+  c->m16 = cost16.stats();
   c->db = d_desc;
   // the group table of the consumer kernels (vsmatch_kernels.h, group_min_kernel): reads every
   // descriptor once, now
