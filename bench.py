@@ -74,7 +74,7 @@ CYC_XOR, CYC_BCNT = 2.32, 4.61
 PEAK_TLANEOPS = 1024 * 64 * F_MAX / (8 * CYC_XOR + 8 * CYC_BCNT) * LANE_OPS_PER_COMP / 1e12
 NOMINAL_TLANEOPS = 256 * 64 * F_MAX / 1e12  # 39.32, BASELINE.md 4
 PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r03", "r02")]  # the newest committed PMC summary wins
-KERNEL_SOURCES = ("mfma_scan.h", "vsmatch_kernels.h", "vsmatch.hip")  # what the committed counters were taken from
+KERNEL_SOURCES = ("mfma_scan.h", "mfma16_scan.h", "vsmatch_kernels.h", "vsmatch.hip")  # what the committed counters were taken from
 BLOCK = 4096  # pairs per block of the block-cyclic partition (sfm_pairs.BLOCK)
 
 
@@ -612,9 +612,13 @@ def main():
     assert 0 < scan_comps <= comps_rank, (scan_comps, comps_rank)
     achieved = fwd["comparisons"] * FLOP_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
     fwd_laneops = fwd["comparisons"] * LANE_OPS_PER_COMP / (fwd["scan_ms"] * 1e-3) / 1e12
+    fwd_kernel = m.last_scan_kernel(0)
     roofline = {
-        "bound": "mfma", "kernel": "mfma_scan_kernel<8,1> (forward scans, the dominant kernel: FP4 +-1 dot products on "
-                                   "v_mfma_f32_32x32x64_f8f6f4, one-wave workgroups, 256-query tiles)",
+        "bound": "mfma",
+        "kernel": ("mfma16_scan_kernel (forward scans, the dominant kernel: FP4 dot products on v_mfma_f32_16x16x128_f8f6f4, "
+                   "one-wave workgroups, balanced tiles of at most 224 queries; csrc/mfma16_scan.h)" if fwd_kernel == 3 else
+                   "mfma_scan_kernel<8,1> (forward scans, the dominant kernel: FP4 +-1 dot products on "
+                   "v_mfma_f32_32x32x64_f8f6f4, one-wave workgroups, 256-query tiles)"),
         "achieved": achieved, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_TFLOPS,
         "x_popcount_valu_roofline_measured_issue_rate": fwd_laneops / PEAK_TLANEOPS,
         "x_popcount_valu_roofline_nominal_64_lanes_per_clk": fwd_laneops / NOMINAL_TLANEOPS,
@@ -623,7 +627,7 @@ def main():
         "pairs_per_launch": min(P, 32768),
         "algorithmic": "512 FLOP (256 FP4 multiply-adds, exact in the f32 accumulator) per 256-bit comparison x "
                        "comparisons really evaluated per launch (N1*N2 per pair for the forward scan); "
-                       "peak = 1024 SIMDs x 4096 FLOP/clk (one 32x32x64 FP4 MFMA per 32 cycles) x 2.4 GHz = 10.07 PFLOP/s "
+                       "peak = 1024 SIMDs x 4096 FLOP/clk (one 32x32x64 FP4 MFMA per 32 cycles, or one 16x16x128 per 16) x 2.4 GHz = 10.07 PFLOP/s "
                        "= 19.66 T comparisons/s; the popcount (v_xor + v_bcnt) roofline the path was first built to is "
                        "2.84 T comparisons/s at measured issue rates, 2.46 T nominal",
         "kernel_gcomps": fwd["comparisons"] / (fwd["scan_ms"] * 1e-3) / 1e9,

@@ -331,6 +331,10 @@ int vsm_last_scan_stats(vsm_ctx* ctx, double* ms, uint64_t* launches, uint64_t* 
  * row points at are scanned backward; the cross-check reads nothing else). */
 int vsm_last_scan_stats_kind(vsm_ctx* ctx, int kind, double* ms, uint64_t* launches,
                              uint64_t* comparisons);
+/* Which scan kernel the last launch of that kind was: 0 = none yet, 1 = the popcount scan (v_xor + v_bcnt), 2 = the
+ * matrix-core scan on v_mfma_f32_32x32x64_f8f6f4, 3 = on v_mfma_f32_16x16x128_f8f6f4 (csrc/mfma16_scan.h).  bench.py
+ * names the kernel its roofline line is about by it. */
+int vsm_last_scan_kernel(vsm_ctx* ctx, int kind);
 /* Enable/disable the event timing above (off by default; costs two events per launch). */
 int vsm_set_profiling(vsm_ctx* ctx, int enabled);
 /* Kernel variant selector for experiments and for the parity tests, which drive every kernel shape

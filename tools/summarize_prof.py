@@ -10,7 +10,6 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
-DOMINANT = "mfma_scan_kernel<8, 1>"
 XCDS, SIMDS = 8, 1024
 
 
@@ -22,6 +21,8 @@ cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os
 line = json.loads(open(os.path.join(src, "trace.json")).readline())
 pairs = int(line["config"]["pairs_per_rank_per_step"])
 top = q(os.path.join(src, "trace", "t_results.db"), "select * from top_kernels")
+# the forward scan of the batch: the 16x16x128 kernel (csrc/mfma16_scan.h) or the 32x32x64 one, whichever the library chose
+DOMINANT = max(("mfma16_scan_kernel", "mfma_scan_kernel<8, 1"), key=lambda k: sum(t[2] for t in top if k in t[0]))
 with open(os.path.join(dst, "kernel_trace_stats.txt"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python3 {cmd}   ({pairs} pairs per launch, the bench default)\n")
     f.write("# columns: kernel | calls | total_us | avg_us | percent\n")
@@ -97,11 +98,11 @@ if v and s.get("SQ_INSTS_MFMA_per_launch"):
 # what code the counters were taken from: bench.py marks them stale when the sources have changed since
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
-for name in ("mfma_scan.h", "vsmatch_kernels.h", "vsmatch.hip"):
+for name in ("mfma_scan.h", "mfma16_scan.h", "vsmatch_kernels.h", "vsmatch.hip"):
     with open(os.path.join(ROOT, "visual-slam_amd", "csrc", name), "rb") as f:
         h.update(f.read())
 s["kernel_sources_sha256"] = h.hexdigest()
-s["kernel_sources"] = "visual-slam_amd/csrc/{mfma_scan.h, vsmatch_kernels.h, vsmatch.hip}, concatenated in this order"
+s["kernel_sources"] = "visual-slam_amd/csrc/{mfma_scan.h, mfma16_scan.h, vsmatch_kernels.h, vsmatch.hip}, concatenated in this order"
 
 # the popcount formulation (north_star's: v_xor + v_bcnt, knob bit 25) under the same command: VALU utilisation evidence
 pc = {}

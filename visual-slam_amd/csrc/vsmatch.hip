@@ -214,6 +214,7 @@ struct vsm_ctx {
   // per kind: 0 = full / forward scans, 1 = pruned backward scans
   double scan_ms[2] = {0, 0};
   u64 scan_launches[2] = {0, 0}, scan_comps[2] = {0, 0};
+  int scan_kernel[2] = {0, 0};  // vsm_last_scan_kernel
   std::vector<int> ev_kind;
   int variant = 0;
 };
@@ -508,6 +509,7 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
 #undef VSM_LAUNCH_MC
   HIP_TRY(hipGetLastError());
   if (timed) HIP_TRY(hipEventRecord(e1, c->stream));
+  c->scan_kernel[kind] = m16 ? 3 : sh.mfma ? 2 : 1;
   c->scan_launches[kind]++;
   c->scan_comps[kind] += comps;
   return VSM_OK;
@@ -803,6 +805,12 @@ int vsm_last_scan_stats_kind(vsm_ctx* c, int kind, double* ms, uint64_t* launche
   if (launches) *launches = c->scan_launches[kind];
   if (comparisons) *comparisons = c->scan_comps[kind];
   return VSM_OK;
+}
+
+int vsm_last_scan_kernel(vsm_ctx* c, int kind) {
+  if (!c || kind < 0 || kind > 1) return 0;
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  return c->scan_kernel[kind];
 }
 
 int vsm_db_upload(vsm_ctx* c, const uint64_t* desc, const uint32_t* offsets, size_t n_img) {

@@ -25,7 +25,7 @@ VSM_MAX_SET = 1 << 23
 SYMBOLS = (
     "vsm_version", "vsm_last_error", "vsm_create", "vsm_destroy", "vsm_stream",
     "vsm_match_pair", "vsm_match_pair_noalloc", "vsm_nn2", "vsm_nn2_device", "vsm_db_upload", "vsm_db_attach",
-    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_db_upload_multi", "vsm_match_pairs_multi", "vsm_last_scan_stats", "vsm_last_scan_stats_kind",
+    "vsm_match_pairs", "vsm_match_pairs_device", "vsm_db_upload_multi", "vsm_match_pairs_multi", "vsm_last_scan_stats", "vsm_last_scan_stats_kind", "vsm_last_scan_kernel",
     "vsm_set_profiling",
     "vsm_set_variant", "vsm_accept_limit",
     "vsm_match_landmarks",
@@ -100,6 +100,7 @@ def lib():
             L.vsm_match_pairs_multi.argtypes = [C.POINTER(_vp), _sz, _vp, _sz, C.c_int, C.c_double, _vp, _vp, _sz,
                                                 C.POINTER(_sz)]
             L.vsm_last_scan_stats.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            L.vsm_last_scan_kernel.argtypes = [_vp, C.c_int]
             L.vsm_last_scan_stats_kind.argtypes = [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             L.vsm_set_profiling.argtypes = [_vp, C.c_int]
             L.vsm_set_variant.argtypes = [_vp, C.c_int]
@@ -495,6 +496,10 @@ class Matcher:
         else:
             _check(lib().vsm_last_scan_stats_kind(self._h, int(kind), C.byref(ms), C.byref(n), C.byref(comps)))
         return {"scan_ms": ms.value, "launches": n.value, "comparisons": comps.value}
+
+    def last_scan_kernel(self, kind: int = 0) -> int:
+        """0 none yet, 1 popcount scan, 2 matrix cores 32x32x64, 3 matrix cores 16x16x128 (vsm_last_scan_kernel)."""
+        return int(lib().vsm_last_scan_kernel(self._h, int(kind)))
 
 
 class MultiMatcher:
