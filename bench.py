@@ -1053,7 +1053,7 @@ def main():
                             "matches_per_pair": tot / len(rp)}
                 if name == "matrix_core":
                     ach = k0["comparisons"] * FLOP_PER_COMP / (k0["scan_ms"] * 1e-3) / 1e12
-                    rl["roofline"] = {"bound": "mfma", "kernel": "mfma_scan_kernel<8,1> (forward scans)", "achieved": ach,
+                    rl["roofline"] = {"bound": "mfma", "kernel": ("mfma16_scan_kernel" if mr.last_scan_kernel(0) == 3 else "mfma_scan_kernel<8,1>") + " (forward scans)", "achieved": ach,
                                       "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_TFLOPS,
                                       "launches": k0["launches"], "avg_launch_ms": k0["scan_ms"] / max(1, k0["launches"])}
                     chk = rrng.choice(len(rp), size=24, replace=False)

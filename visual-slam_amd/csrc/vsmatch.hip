@@ -555,7 +555,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
   // Pruned backward pass (nominate_kernel): only for unsplit scans and images that fit the LDS bitmap.
   const bool prune = sh.splits == 1 && stride <= NOMINATE_MAX_STRIDE && !(c->variant & KNOB_NO_PRUNE);
   if (prune) VSM_TRY(c->qlist.reserve(chunk * stride * sizeof(u32)));
-  if (prune) VSM_TRY(c->flist.reserve(chunk * stride * sizeof(u32)));
+  if (prune) VSM_TRY(c->flist.reserve(chunk * stride * sizeof(uint2)));
   // accept masks (one bit per forward row) and the accept table on the device, for the matrix-core
   // forward scan's epilogue; the popcount scans do not write masks (nominate_kernel then reads every row)
   const bool masks = prune && sh.mfma && sh.adaptive;
@@ -599,12 +599,12 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     if (prune) {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, acc));
       hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, (u32*)c->flist.p, d_comps + 1, (const u32*)acc.mask);
+                         stride, (u32*)c->qlist.p, (uint2*)c->flist.p, d_comps + 1, (const u32*)acc.mask);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
       hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
-                         (const u32*)c->flist.p, stride, prm, d_counts, desc,
+                         (const uint2*)c->flist.p, stride, prm, d_counts, desc,
                          (sh.mfma ? 1u : 0u) | (shb.mfma ? 2u : 0u), gmin);
     } else {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, 2 * (u64)n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim));
@@ -623,8 +623,8 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        d_out_offsets, first, d_running);
     HIP_TRY(hipGetLastError());
     if (prune)
-      hipLaunchKernelGGL(fill_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
-                         (const u32*)c->flist.p, stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);
+      hipLaunchKernelGGL(fill_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, d_out_offsets, first,
+                         d_out_pairs, (u64)cap_pairs);
     else
       hipLaunchKernelGGL(fill_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, 1u,
                          (u32)split_stride, prm, d_out_offsets, first, d_out_pairs, (u64)cap_pairs);

@@ -740,7 +740,7 @@ __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
 // Pruned backward pass.  The cross-check (keypoints.h:354-360) only ever looks at
 // backward results of columns j = best1[i] of forward-ACCEPTED rows i, so only
 // those columns need a backward scan.  Per pair (one 256-thread workgroup):
-//  1. the forward-accepted rows i, ascending, go to flist[p*stride ...) -- from the accept bits the
+//  1. the forward-accepted rows i, ascending, go to flist[p*stride ...) (with the key of their best) -- from the accept bits the
 //     matrix-core forward scan left (mfma_scan.h store_accept_mask: 4 bytes per 32 rows instead
 //     of every 8-byte result) or, after a popcount scan, from the results themselves;
 //     after a matrix-core scan "accepted" is by the scan's upper bound of the second best, which can
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
                                                        uint2* __restrict__ scratch,
                                                        AcceptParams prm, u32 stride,
                                                        u32* __restrict__ qlist,
-                                                       u32* __restrict__ flist,
+                                                       uint2* __restrict__ flist,
                                                        u64* __restrict__ comps,
                                                        const u32* __restrict__ accmask) {
   __shared__ uint16_t lut[260];
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   for (u32 w = threadIdx.x; w < words; w += 256) bitmap[w] = 0;
   __syncthreads();
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  u32* list = flist + (size_t)p * stride;
+  uint2* list = flist + (size_t)p * stride;  // entries (row i, key of its best: distance << IDX_BITS | column), see step 2
   // position of this thread's `cnt` items among the workgroup's, after `acc` earlier ones; returns
   // the new total (two barriers)
   auto place = [&](u32 cnt, u32 acc, u32& pos) {
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
         const u32 i = w * 32 + (u32)__builtin_ctz(bits);
         bits &= bits - 1;
         if (pos < NOMINATE_LDS_LIST) slist[pos] = i;
-        list[pos] = i;
+        else list[pos].x = i;
         pos++;
       }
     }
@@ -821,16 +821,19 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
       acc = place(hit ? 1u : 0u, acc, pos);
       if (hit) {
         if (pos < NOMINATE_LDS_LIST) slist[pos] = i;
-        list[pos] = i;
+        else list[pos].x = i;
       }
     }
   }
   __syncthreads();  // the list is read below by other threads
-  // mark the columns of the listed rows
+  // mark the columns of the listed rows; the list entry takes the key along, so that the consumer kernels
+  // read (row, column, distance) in one coalesced 8-byte load instead of the row's result at a random place
   for (u32 k = threadIdx.x; k < acc; k += 256) {
-    const u32 i = k < NOMINATE_LDS_LIST ? slist[k] : list[k];
-    const u32 j = scratch[f.out_off + i].x & IDX_MASK;
+    const u32 i = k < NOMINATE_LDS_LIST ? slist[k] : list[k].x;
+    const u32 key = scratch[f.out_off + i].x;
+    const u32 j = key & IDX_MASK;
     atomicOr(&bitmap[j >> 5], 1u << (j & 31));
+    list[k] = make_uint2(i, key);
   }
   __syncthreads();
   u32 done = 0;
@@ -854,104 +857,107 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   }
 }
 
-// Cross-check of forward-accepted row flist[k] of pair p (the forward accept test was applied by
-// nominate_kernel): its backward result must be accepted and point back at it.
-__device__ __forceinline__ bool cross_check_listed(const uint2* __restrict__ scratch, const Job& f, const Job& b,
-                                                   u32 i, const uint16_t* lut, int threshold, u32& j) {
-  j = scratch[f.out_off + i].x & IDX_MASK;
-  u32 back;
-  return accepted(scratch[b.out_off + j], lut, threshold, back) && back == i;
-}
-
 // count_kernel / fill_kernel over the forward-accepted rows only (pruned path, unsplit scans).
+//
+// count_list_kernel: cross-check (keypoints.h:354-360) of the listed rows of pair p -- row i = flist[k].x with its
+// best column j: the backward result of j must be accepted and point back at i -- then, for results of the
+// matrix-core scan (`refine` bit 0: forward, bit 1: backward), the exact second best of the rows that are left
+// (nominate_kernel lists rows by the scan's upper bound; an upper bound can only list too many rows, never too
+// few; a third of the listed rows of a dense batch are gone after the cross-check) -- most are settled by the
+// group table without reading a descriptor (second_certified).  The matches (i, j) are written, in order, over
+// the first results of the pair's own FORWARD scratch range, which nothing reads afterwards: entry k of the list
+// names a row i >= k and goes to a place <= k, a turn of the loop reads before it writes, and later turns read rows
+// beyond every place written so far.  fill_list_kernel then only copies them to their place in the output:
+// per listed row one random 8-byte read (the backward result) and two table bytes instead of the six random reads of
+// the rounds before (forward result in three kernels, backward result twice): nominate + count_list + fill_list
+// 0.91 -> 0.64 ms on the real-like batch (fill_list 253 -> 27 us, count_list 390 -> 348 us).
 __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__ jobs,
                                                          uint2* __restrict__ scratch,
-                                                         const u32* __restrict__ flist, u32 stride,
+                                                         const uint2* __restrict__ flist, u32 stride,
                                                          AcceptParams prm, u32* __restrict__ counts,
                                                          const u32x4* __restrict__ desc, u32 refine,
                                                          const uint8_t* __restrict__ gmin) {
+  // U entries per thread and turn, their loads issued together (list entries, then the backward results, then the
+  // table bytes).  Measured on the real-like batch (19900 pairs, ~700 listed rows each; tools/prof_real_like.sh):
+  // U = 1: 348 us, 2: 360 us, 8: 379 us -- the kernel is not waiting on dependent reads, more in flight does not help.
+  constexpr int U = 1;
   __shared__ uint16_t lut[260];
-  __shared__ u32 total;
-  if (threadIdx.x == 0) total = 0;
+  __shared__ u32 wave_cnt[U][4];
   load_lut(lut, prm);
   const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
-  const u32* list = flist + (size_t)blockIdx.x * stride;
-  u32 mine = 0;
-  for (u32 k = threadIdx.x; k < f.pad1; k += blockDim.x) {
-    u32 j;
-    const u32 i = list[k];
-    bool hit = cross_check_listed(scratch, f, b, i, lut, prm.threshold, j);
-    if (hit && refine) {  // bit 0: forward results come from the matrix-core scan, bit 1: backward ones
-      // Results of the matrix-core scan: exact second bests before the pair counts -- the forward
-      // one of row i (nominate_kernel lists rows by the scan's upper bound and leaves it to this
-      // point, where only the rows that survive the cross-check are left: a third fewer on a dense
-      // batch; an upper bound can only list too many rows, never too few), then the backward
-      // one of column j.  Written back, so that fill_list_kernel sees finished results; each has
-      // this one writer (row i is this thread's, column j points back at it).
-      // Most results are settled by the group table without reading a descriptor (second_certified).
-      if (refine & 1u) {
-        const uint2 vf = scratch[f.out_off + i];
-        if (!second_certified(gmin, f.t_off, vf, lut)) {
-          const u32 sf = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, vf);
-          if (sf != min(vf.y >> IDX_BITS, 256u)) scratch[f.out_off + i].y = sf << IDX_BITS;
-          hit = sf >= (u32)lut[vf.x >> IDX_BITS];
-        }
-      }
-      if (hit && (refine & 2u)) {
-        const uint2 v = scratch[b.out_off + j];
-        if (!second_certified(gmin, b.t_off, v, lut)) {
-          const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, v);
-          if (s2 != min(v.y >> IDX_BITS, 256u)) scratch[b.out_off + j].y = s2 << IDX_BITS;
-          hit = s2 >= (u32)lut[v.x >> IDX_BITS];
-        }
-      }
-    }
-    mine += hit ? 1u : 0u;
-  }
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
-  __syncthreads();
-  if (threadIdx.x == 0) counts[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(256) void fill_list_kernel(const Job* __restrict__ jobs,
-                                                        const uint2* __restrict__ scratch,
-                                                        const u32* __restrict__ flist, u32 stride,
-                                                        AcceptParams prm, const u64* __restrict__ offsets,
-                                                        u64 first, int2* __restrict__ out_pairs, u64 cap_pairs) {
-  __shared__ uint16_t lut[260];
-  __shared__ u32 wave_cnt[4];
-  load_lut(lut, prm);
-  const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
-  const u64 o0 = offsets[first + blockIdx.x];
-  if (offsets[first + blockIdx.x + 1] == o0) return;  // uniform: nothing to write
-  const u32* list = flist + (size_t)blockIdx.x * stride;
+  const uint2* list = flist + (size_t)blockIdx.x * stride;
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 done = 0;
-  for (u32 base = 0; base < f.pad1; base += 256) {
-    const u32 k = base + threadIdx.x;
-    u32 i = 0, j = 0;
-    bool hit = false;
-    if (k < f.pad1) {
-      i = list[k];
-      u32 jf;
-      hit = accepted(scratch[f.out_off + i], lut, prm.threshold, jf) &&  // finished by count_list_kernel
-            cross_check_listed(scratch, f, b, i, lut, prm.threshold, j);
+  for (u32 base = 0; base < f.pad1; base += 256 * U) {
+    uint2 e[U], vb[U];
+    bool hit[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const u32 k = base + u * 256 + threadIdx.x;
+      e[u] = k < f.pad1 ? list[k] : make_uint2(0u, 0u);
     }
-    const u64 m = __ballot(hit);
-    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const u32 k = base + u * 256 + threadIdx.x;
+      vb[u] = k < f.pad1 ? scratch[b.out_off + (e[u].y & IDX_MASK)] : make_uint2(KEY_INIT, KEY_INIT);
+    }
+    bool cf[U], cb[U];  // settled by the group table
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const u32 k = base + u * 256 + threadIdx.x;
+      u32 back;
+      hit[u] = k < f.pad1 && accepted(vb[u], lut, prm.threshold, back) && back == e[u].x;
+      cf[u] = !(hit[u] && (refine & 1u)) || second_certified(gmin, f.t_off, make_uint2(e[u].y, 0u), lut);
+      cb[u] = !(hit[u] && (refine & 2u)) || second_certified(gmin, b.t_off, vb[u], lut);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {  // the few the table does not settle: the group's rows again
+      const u32 i = e[u].x, j = e[u].y & IDX_MASK;
+      if (!cf[u]) {
+        const uint2 vf = scratch[f.out_off + i];
+        const u32 sf = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, vf);
+        hit[u] = sf >= (u32)lut[vf.x >> IDX_BITS];
+      }
+      if (hit[u] && !cb[u]) {
+        const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, vb[u]);
+        hit[u] = s2 >= (u32)lut[vb[u].x >> IDX_BITS];
+      }
+    }
+    u32 rank[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const u64 m = __ballot(hit[u]);
+      rank[u] = (u32)__popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_cnt[u][wave] = (u32)__popcll(m);
+    }
+    __syncthreads();  // every read of this turn is through
+    u32 at = done;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      u32 before = at;
+      for (u32 w = 0; w < 4; w++) {
+        if (w < wave) before += wave_cnt[u][w];
+        at += wave_cnt[u][w];
+      }
+      if (hit[u]) scratch[f.out_off + before + rank[u]] = make_uint2(e[u].x, e[u].y & IDX_MASK);
+    }
+    done = at;
     __syncthreads();
-    u32 before = done, all = 0;
-    for (u32 w = 0; w < 4; w++) {
-      if (w < wave) before += wave_cnt[w];
-      all += wave_cnt[w];
-    }
-    if (hit) {
-      const u64 pos = o0 + before + (u32)__popcll(m & ((1ull << lane) - 1ull));
-      if (pos < cap_pairs) out_pairs[pos] = make_int2((int)i, (int)j);
-    }
-    done += all;
-    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = done;
+}
+
+// The matches count_list_kernel left at the head of the pair's forward scratch range, to their place in the output.
+__global__ __launch_bounds__(256) void fill_list_kernel(const Job* __restrict__ jobs,
+                                                        const uint2* __restrict__ scratch,
+                                                        const u64* __restrict__ offsets,
+                                                        u64 first, int2* __restrict__ out_pairs, u64 cap_pairs) {
+  const u64 o0 = offsets[first + blockIdx.x];
+  const u32 n = (u32)(offsets[first + blockIdx.x + 1] - o0);
+  const uint2* src = scratch + jobs[blockIdx.x].out_off;
+  for (u32 k = threadIdx.x; k < n; k += 256) {
+    const uint2 e = src[k];
+    if (o0 + k < cap_pairs) out_pairs[o0 + k] = make_int2((int)e.x, (int)e.y);
   }
 }
 
