@@ -877,71 +877,82 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
                                                          AcceptParams prm, u32* __restrict__ counts,
                                                          const u32x4* __restrict__ desc, u32 refine,
                                                          const uint8_t* __restrict__ gmin) {
-  // U entries per thread and turn, their loads issued together (list entries, then the backward results, then the
-  // table bytes).  Measured on the real-like batch (19900 pairs, ~700 listed rows each; tools/prof_real_like.sh):
-  // U = 1: 348 us, 2: 360 us, 8: 379 us -- the kernel is not waiting on dependent reads, more in flight does not help.
-  constexpr int U = 1;
+  // The results the table does not settle (~5 % on a dense batch) go to a queue in LDS and are refined by TEAMS of 16
+  // lanes, one group row per lane (as merge_refine_wide_kernel does): with refine_second called where it is needed,
+  // nearly every wave had a lane that needed it and ran its sixteen-row loop for that lane alone -- 890 VALU
+  // instructions per wave, most of them in these loops (rocprofv3 SQ_INSTS_VALU, real-like batch).
+  // (Eight / two entries per thread with their loads issued together were measured too: 379 / 360 us against 348.)
   __shared__ uint16_t lut[260];
-  __shared__ u32 wave_cnt[U][4];
+  __shared__ u32 wave_cnt[4];
+  __shared__ u32 n_tasks;
+  __shared__ u32 task_q[512], task_t[512], task_nt[512], task_key[512], task_who[512];  // who: thread << 1 | direction
+  __shared__ u32 reject[256];
   load_lut(lut, prm);
   const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
   const uint2* list = flist + (size_t)blockIdx.x * stride;
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u32 done = 0;
-  for (u32 base = 0; base < f.pad1; base += 256 * U) {
-    uint2 e[U], vb[U];
-    bool hit[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const u32 k = base + u * 256 + threadIdx.x;
-      e[u] = k < f.pad1 ? list[k] : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const u32 k = base + u * 256 + threadIdx.x;
-      vb[u] = k < f.pad1 ? scratch[b.out_off + (e[u].y & IDX_MASK)] : make_uint2(KEY_INIT, KEY_INIT);
-    }
-    bool cf[U], cb[U];  // settled by the group table
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const u32 k = base + u * 256 + threadIdx.x;
+  for (u32 base = 0; base < f.pad1; base += 256) {
+    if (threadIdx.x == 0) n_tasks = 0;
+    reject[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 k = base + threadIdx.x;
+    u32 i = 0, j = 0;
+    bool hit = false;
+    if (k < f.pad1) {
+      const uint2 e = list[k];
+      i = e.x;
+      j = e.y & IDX_MASK;
+      const uint2 vb = scratch[b.out_off + j];
       u32 back;
-      hit[u] = k < f.pad1 && accepted(vb[u], lut, prm.threshold, back) && back == e[u].x;
-      cf[u] = !(hit[u] && (refine & 1u)) || second_certified(gmin, f.t_off, make_uint2(e[u].y, 0u), lut);
-      cb[u] = !(hit[u] && (refine & 2u)) || second_certified(gmin, b.t_off, vb[u], lut);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {  // the few the table does not settle: the group's rows again
-      const u32 i = e[u].x, j = e[u].y & IDX_MASK;
-      if (!cf[u]) {
-        const uint2 vf = scratch[f.out_off + i];
-        const u32 sf = refine_second(desc + 2 * (size_t)(f.q_off + i), desc + 2 * (size_t)f.t_off, f.nt, f.nt, vf);
-        hit[u] = sf >= (u32)lut[vf.x >> IDX_BITS];
+      hit = accepted(vb, lut, prm.threshold, back) && back == i;
+      if (hit && (refine & 1u) && !second_certified(gmin, f.t_off, make_uint2(e.y, 0u), lut)) {
+        const u32 t = atomicAdd(&n_tasks, 1u);
+        task_q[t] = f.q_off + i;
+        task_t[t] = f.t_off;
+        task_nt[t] = f.nt;
+        task_key[t] = e.y;
+        task_who[t] = threadIdx.x << 1;
       }
-      if (hit[u] && !cb[u]) {
-        const u32 s2 = refine_second(desc + 2 * (size_t)(b.q_off + j), desc + 2 * (size_t)b.t_off, b.nt, b.nt, vb[u]);
-        hit[u] = s2 >= (u32)lut[vb[u].x >> IDX_BITS];
+      if (hit && (refine & 2u) && !second_certified(gmin, b.t_off, vb, lut)) {
+        const u32 t = atomicAdd(&n_tasks, 1u);
+        task_q[t] = b.q_off + j;
+        task_t[t] = b.t_off;
+        task_nt[t] = b.nt;
+        task_key[t] = vb.x;
+        task_who[t] = threadIdx.x << 1 | 1u;
       }
     }
-    u32 rank[U];
+    __syncthreads();
+    // a team per task: the fifteen group mates of the best (refine_second: rows b0 + (l & 3) + 8 (l >> 2) of the
+    // best's 32-row step, unsplit scan); a closer one than the accept test's least second best rejects the entry
+    // (the stored second best passed the test already)
+    const u32 nt_ = n_tasks, team = threadIdx.x >> 4, l = threadIdx.x & 15;
+    for (u32 t = team; t < nt_; t += 16) {
+      const u32 key = task_key[t], idx = key & IDX_MASK, d = key >> IDX_BITS, ntr = task_nt[t];
+      const u32 r = (idx & ~31u) + (idx & 4u) + (l & 3u) + 8u * (l >> 2);
+      const u32x4* dq = desc + 2 * (size_t)task_q[t];
+      const u32x4* dt = desc + 2 * ((size_t)task_t[t] + min(r, ntr - 1));
+      const u32x4 qa = dq[0], qb = dq[1], ta = dt[0], tb = dt[1];
+      u32 dr = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+               __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+      dr = (r < ntr && r != idx) ? dr : 0x1ffu;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const u64 m = __ballot(hit[u]);
-      rank[u] = (u32)__popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_cnt[u][wave] = (u32)__popcll(m);
+      for (int o = 1; o < 16; o <<= 1) dr = min(dr, (u32)__shfl_xor((int)dr, o, 16));
+      if (l == 0 && dr < (u32)lut[min(d, 256u)]) reject[task_who[t] >> 1] = 1;
     }
+    __syncthreads();
+    hit = hit && !reject[threadIdx.x];
+    const u64 m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
     __syncthreads();  // every read of this turn is through
-    u32 at = done;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      u32 before = at;
-      for (u32 w = 0; w < 4; w++) {
-        if (w < wave) before += wave_cnt[u][w];
-        at += wave_cnt[u][w];
-      }
-      if (hit[u]) scratch[f.out_off + before + rank[u]] = make_uint2(e[u].x, e[u].y & IDX_MASK);
+    u32 before = done, all = 0;
+    for (u32 w = 0; w < 4; w++) {
+      if (w < wave) before += wave_cnt[w];
+      all += wave_cnt[w];
     }
-    done = at;
+    if (hit) scratch[f.out_off + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(i, j);
+    done += all;
     __syncthreads();
   }
   if (threadIdx.x == 0) counts[blockIdx.x] = done;
