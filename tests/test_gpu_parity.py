@@ -274,6 +274,49 @@ def test_batched_pruned_path_under_many_accept_tests(thr, ratio):
         assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], want), (thr, ratio, k)
 
 
+def test_the_16x16_forward_scan_at_every_tile_and_tail_boundary():
+    """csrc/mfma16_scan.h forced on (knob bit 24) on a RAGGED real-like database whose image sizes sit on its
+    boundaries: 16-query blocks, balanced tiles of at most 224 queries (1 .. 3 tiles, every instantiation 2 .. 14
+    blocks), supersteps of 64 train rows and the half-step tail (0 .. 63 rows behind the last superstep), empty
+    images.  All pairs, both scan directions of the unpruned path and the pruned path with its accept masks, against
+    the 32x32x64 kernel (bit 19) and against the oracle."""
+    sizes = [0, 1, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 95, 96, 97, 111, 127, 128, 129, 159, 161, 191, 193, 223, 224, 225,
+             255, 257, 287, 289, 319, 321, 351, 353, 383, 385, 415, 417, 447, 448, 449, 479, 481, 511, 513, 543, 545, 671, 673, 700]
+    rng = np.random.default_rng(77)
+    base = np.concatenate(cases.ex3())
+    parts = []
+    for n in sizes:
+        d = base[rng.integers(0, len(base), size=n)].copy()
+        d[:, 0] ^= np.uint64(1) << rng.integers(0, 64, size=n).astype(np.uint64)  # near neighbours, a few exact duplicates
+        parts.append(d)
+    db = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    pairs = np.array([(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j], np.uint32)
+    with vsm.Matcher(0) as mm:
+        mm.db_upload(db, off)
+        res = {}
+        for name, variant in (("m16", M16 | TILE256 | 8), ("m16_unpruned", M16 | NO_PRUNE | TILE256 | 8), ("m32", M16_OFF | TILE256 | 8)):
+            mm.set_variant(variant)
+            res[name] = mm.match_pairs(pairs, 70, 1.2)
+            assert mm.last_scan_kernel(0) == (2 if name == "m32" else 3), name
+        mm.set_variant(M16 | TILE256 | 8)  # (256-query tiles forced: small images would otherwise get 128-query tiles, which the 16x16 kernel does not replace)
+        loose = mm.match_pairs(pairs, 256, 1.0)  # every query tracked to distance 256
+        mm.set_variant(M16_OFF | TILE256 | 8)
+        loose32 = mm.match_pairs(pairs, 256, 1.0)
+    for name in ("m16_unpruned", "m32"):
+        assert np.array_equal(res["m16"][0], res[name][0]) and np.array_equal(res["m16"][1], res[name][1]), name
+    assert np.array_equal(loose[0], loose32[0]) and np.array_equal(loose[1], loose32[1])
+    o = binding.port()
+    offs, out = res["m16"]
+    assert int(offs[-1]) > 5000
+    for k in rng.choice(len(pairs), size=400, replace=False).tolist():
+        i, j = pairs[k]
+        want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2)
+        assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], want), (sizes[i], sizes[j])
+        want = o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 256, 1.0)
+        assert np.array_equal(loose[1][int(loose[0][k]):int(loose[0][k + 1])], want), (sizes[i], sizes[j])
+
+
 def test_nn2_vs_oracle(m):
     for variant in (0, 8, 1, TILE64 | 8, TILE128 | 8, POPCOUNT | 8, POPCOUNT | INT_KEYS, POP_LAT | 1, FLIP | 8, FLIP | TILE64 | 8, FLIP | 1, M16 | 8):
         m.set_variant(variant)

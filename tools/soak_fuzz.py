@@ -31,7 +31,9 @@ matcher = importlib.import_module("visual-slam_amd.matcher")
 TILE256, TILE128, TILE64 = 0x40000000, 0x20000000, 0x10000000
 POPCOUNT, POP_BACK, NO_PRUNE, INT_KEYS = 1 << 25, 1 << 26, 1 << 16, 1 << 17
 RUN = lambda j: j << 20  # noqa: E731
+M16, M16_OFF, FLIP = 0x1000000, 0x80000, 0x40000  # round 3: always / never the 16x16x128 forward scan; the other operand codes
 VARIANTS = [0, 0, 0, 0, TILE256, TILE128, TILE64, NO_PRUNE, POP_BACK, POPCOUNT | TILE256, POPCOUNT | INT_KEYS | TILE64,
+            M16 | TILE256, M16 | TILE256, M16 | TILE256 | 8, M16 | NO_PRUNE | TILE256, M16_OFF, FLIP, FLIP | TILE128, FLIP | TILE64,
             RUN(2) | TILE256, RUN(3) | TILE256, RUN(4), RUN(8) | TILE256, RUN(8) | NO_PRUNE | TILE256, 0x0208, 0x0308, 8, 4, 1]
 
 
@@ -73,7 +75,8 @@ def single_pairs(budget, seed):
     real = real_pool()
     m = matcher.Matcher(0)
     o = binding.port()
-    variants = [0, 0, 0, 1, 4, 8, 0x0301, 0x0308, 0x0208, 0x1708, POPCOUNT | 8, POPCOUNT | 1, TILE64 | 8, TILE128 | 8, TILE256 | 8]
+    variants = [0, 0, 0, 1, 4, 8, 0x0301, 0x0308, 0x0208, 0x1708, POPCOUNT | 8, POPCOUNT | 1, TILE64 | 8, TILE128 | 8, TILE256 | 8,
+                M16 | 8, M16 | TILE256 | 8, FLIP | 8, FLIP | 1]
     t_end = time.time() + budget
     case = 0
     while time.time() < t_end:

@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x4 mfma16_step(const i32x8 a, const i32x8 b, const
 template <int NBQ>
 __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes, const char* __restrict__ tbytes, const Job job,
                                                  u32 q0, u32 lane, uint2* __restrict__ scratch, u32 d_lim,
-                                                 const AcceptMask& acc) {
+                                                 const AcceptMask& acc, const uint16_t* lut) {
   static_assert(NBQ >= 2 && NBQ % 2 == 0, "pairs of blocks share a word of the accept mask");
   const u32 c = lane & 15, g = lane >> 4, h = g & 1;
   u32 m88 = 0x88888888u, c11 = 0x11111111u, m44 = 0x44444444u, m22 = 0x22222222u, m11 = 0x11111111u;
@@ -270,9 +270,11 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
     const u32 qi = q0e + b * 16 + c;
     const bool valid = g == 0 && qi < job.nq;
     if (valid) out[qi] = make_uint2(kb, ks);
-    if (acc.mask) {  // keypoints.h:295-296 on the finished result, one bit per query (store_accept_mask, mfma_scan.h)
+    if (acc.mask) {  // keypoints.h:295-296 on the finished result, one bit per query (store_accept_mask, mfma_scan.h);
+      // the accept table comes from LDS (see the kernel): a global load here cannot move above the stores of the block
+      // before it, the table lookups of a tile's fourteen blocks would wait for memory one after the other
       const u32 d = kb >> IDX_BITS, sd = min(ks >> IDX_BITS, 256u);
-      const bool hit = valid && d < 256u && (int)d < acc.threshold && sd >= (u32)acc.lut[min(d, 256u)];
+      const bool hit = valid && d < 256u && (int)d < acc.threshold && sd >= (u32)lut[min(d, 256u)];
       const u32 m = (u32)__ballot(hit) & 0xffffu;
       if (b & 1) {
         const u32 q_first = q0e + (b - 1) * 16;
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mf
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
     uint2* __restrict__ scratch, u32 tiles_per_job, u32 d_lim, AcceptMask acc) {
   const u32 lane = threadIdx.x & 63;
+  __shared__ uint16_t lut[264];  // AcceptParams::min_second, for the epilogue (one-wave workgroup: no barrier needed beyond the wait)
   u32 j, t;
   if (tiles_per_job) {
     const u32 per_super = 8 * tiles_per_job;
@@ -321,18 +324,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mf
   const Job job = jobs[j];
   const Mfma16Tiling tl = mfma16_tiling(job.nq);
   if (t >= tl.tiles) return;
+  if (acc.mask) {
+    for (u32 k = lane; k < 257; k += 64) lut[k] = acc.lut[k];
+    __syncthreads();
+  }
   const u32 blocks = t < tl.big_tiles ? tl.small + 2 : tl.small;
   const u32 q0 = 16 * (t < tl.big_tiles ? t * (tl.small + 2) : tl.big_tiles * (tl.small + 2) + (t - tl.big_tiles) * tl.small);
   const char* q = (const char*)qbase;
   const char* tr = (const char*)tbase;
   switch (blocks) {
-    case 14: mfma16_scan_tile<14>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
-    case 12: mfma16_scan_tile<12>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
-    case 10: mfma16_scan_tile<10>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
-    case 8: mfma16_scan_tile<8>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
-    case 6: mfma16_scan_tile<6>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
-    case 4: mfma16_scan_tile<4>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
-    default: mfma16_scan_tile<2>(q, tr, job, q0, lane, scratch, d_lim, acc); break;
+    case 14: mfma16_scan_tile<14>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    case 12: mfma16_scan_tile<12>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    case 10: mfma16_scan_tile<10>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    case 8: mfma16_scan_tile<8>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    case 6: mfma16_scan_tile<6>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    case 4: mfma16_scan_tile<4>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    default: mfma16_scan_tile<2>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
   }
 }
 

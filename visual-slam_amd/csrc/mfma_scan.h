@@ -381,9 +381,17 @@ template <int NBMAX, int WAVES = 1, int CODES = VSM_SCAN_CODES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2))) void mfma_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
     u32 splits, u32 split_stride, uint2* __restrict__ scratch, const u32* __restrict__ qlist, u32 tiles_per_job,
-    u32 d_lim, AcceptMask acc, u32 jobs_per_wave) {
+    u32 d_lim, AcceptMask acc_in, u32 jobs_per_wave) {
   const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
+  // The accept table of the epilogue in LDS: a global load there cannot move above the stores of the block before it
+  // (they might alias), so the table lookups of a tile's blocks waited for memory one after the other.
+  __shared__ uint16_t s_lut[264];
+  const AcceptMask acc{s_lut, acc_in.threshold, acc_in.mask};  // (always the LDS copy: read only when there is a mask)
+  if (acc_in.mask) {
+    for (u32 k = threadIdx.x; k < 257; k += 64 * WAVES) s_lut[k] = acc_in.lut[k];
+    __syncthreads();
+  }
   // a wave's jobs [j0, j1) (WAVES == 1: jobs_per_wave consecutive ones, see mfma_scan_run) and the
   // tile t it does of each
   u32 j0, j1, t;
