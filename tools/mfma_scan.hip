@@ -1,7 +1,7 @@
 // tools/mfma_scan.hip -- the matrix-core scan (csrc/mfma_scan.h) against the popcount scan on the
 // same jobs: bitwise comparison of the scratch results and launch times.
 //   hipcc --offload-arch=gfx950 -O3 -I visual-slam_amd/csrc tools/mfma_scan.hip -o /tmp/mfma_scan
-//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim] [plant a true match every k-th descriptor, 0 = none] [real]
+//   /tmp/mfma_scan [descriptors per image] [pairs] [d_lim] [plant a true match every k-th descriptor, 0 = none] [real | synth] [train rows per job]
 // `real` as fifth argument: images are random draws from the reference's 1084 real ORB descriptors
 // (tests/golden/ex3_kd{0,1}.npy, run from the repository root) with ~8 bits flipped per copy.
 #include <hip/hip_runtime.h>
@@ -217,6 +217,7 @@ int main(int argc, char** argv) {
   const u32 n_img = 512, N = argc > 1 ? atoi(argv[1]) : 2000, P = argc > 2 ? atoi(argv[2]) : 4096;
   const u32 d_lim = argc > 3 ? atoi(argv[3]) : 256;
   const u32 plant = argc > 4 ? atoi(argv[4]) : 4;
+  const u32 NT = argc > 6 ? atoi(argv[6]) : N;  // train rows per job (default: the image): the fixed cost of a tile is the time at NT -> 0
   u32* db;
   CK(hipMalloc(&db, (size_t)n_img * N * 32));
   if (argc > 5 && !strcmp(argv[5], "real")) {
@@ -237,8 +238,8 @@ int main(int argc, char** argv) {
   std::vector<Job> jobs(2 * P);
   for (u32 p = 0; p < P; p++) {
     u32 i = (p * 7 + 1) % n_img, j = (p * 13 + 5) % n_img;
-    jobs[2 * p] = {i * N, N, j * N, N, p * 2 * stride, NO_QLIST, 0, 0};
-    jobs[2 * p + 1] = {j * N, N, i * N, N, p * 2 * stride + stride, NO_QLIST, 0, 0};
+    jobs[2 * p] = {i * N, N, j * N, NT, p * 2 * stride, NO_QLIST, 0, 0};
+    jobs[2 * p + 1] = {j * N, N, i * N, NT, p * 2 * stride + stride, NO_QLIST, 0, 0};
   }
   Job* d_jobs;
   CK(hipMalloc(&d_jobs, jobs.size() * sizeof(Job)));
@@ -250,7 +251,7 @@ int main(int argc, char** argv) {
   std::vector<uint2> h_ref(n_scr), h(n_scr);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const double comps = 2.0 * P * (double)N * N;
+  const double comps = 2.0 * P * (double)N * NT;
   const u32 n_jobs = 2 * P;
 
   // reference: the shipped popcount kernel
@@ -316,7 +317,7 @@ int main(int argc, char** argv) {
       } else
       if (v.fmt == 104) {
         const u32 t16 = mfma16_tiles(N);
-        mfma16_scan_kernel<<<dim3(groups * 8 * t16), blk>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, scr, t16, d_lim, AcceptMask{nullptr, 0, nullptr});
+        mfma16_scan_kernel<<<dim3(groups * 8 * t16), blk>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, t16, d_lim, AcceptMask{nullptr, 0, nullptr});
       } else
       if (v.fmt == 84) {
         const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);

@@ -14,7 +14,7 @@ o = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
 m = vsm.Matcher(0)
 m.set_profiling(True)
 ref = None
-for R, tile in ((8 | 0x40000000, 256), (8 | 0x20000000, 128)):
+for R, tile in ((8 | 0x40000000 | 0x80000, "256 (32x32x64)"), (8 | 0x40000000 | 0x1000000, "224 (16x16x128)"), (8 | 0x20000000, "128 (32x32x64)")):
     for splits in (0, 32, 40, 48, 64, 96, 128):
         m.set_variant(R | (splits << 8))
         best = 1e9
@@ -24,4 +24,4 @@ for R, tile in ((8 | 0x40000000, 256), (8 | 0x20000000, 128)):
             best = min(best, m.last_scan_stats()["scan_ms"])
         chk = (int(o[0].sum()), int(o[1].sum()), int(o[2].sum()))
         ref = ref or chk
-        print(f"tile={tile} splits={splits:3d} (0 = the library's choice)  {best:8.2f} ms  {n*n/best/1e6:8.1f} Gcomp/s  frac {n*n*512/best/1e9/10066.3:.3f}  {'ok' if chk == ref else 'MISMATCH'}", flush=True)
+        print(f"tile={tile:16s} splits={splits:3d} (0 = the library's choice)  {best:8.2f} ms  {n*n/best/1e6:8.1f} Gcomp/s  frac {n*n*512/best/1e9/10066.3:.3f}  {'ok' if chk == ref else 'MISMATCH'}", flush=True)

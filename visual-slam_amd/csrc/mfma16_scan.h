@@ -38,10 +38,12 @@ __device__ __forceinline__ f32x4 mfma16_step(const i32x8 a, const i32x8 b, const
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0);
 }
 
-// One tile = 16 * NBQ queries of a job (NBQ even) against its whole train range (unsplit: the host sees to it).
+// One tile = 16 * NBQ queries of a job (NBQ even) against the split's share of its train range (rows [t0, t1); groups,
+// steps and tags count from t0, as in mfma_scan.h).
 template <int NBQ>
 __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes, const char* __restrict__ tbytes, const Job job,
-                                                 u32 q0, u32 lane, uint2* __restrict__ scratch, u32 d_lim,
+                                                 u32 q0, u32 lane, u32 split, u32 splits, u32 split_stride,
+                                                 uint2* __restrict__ scratch, u32 d_lim,
                                                  const AcceptMask& acc, const uint16_t* lut) {
   static_assert(NBQ >= 2 && NBQ % 2 == 0, "pairs of blocks share a word of the accept mask");
   const u32 c = lane & 15, g = lane >> 4, h = g & 1;
@@ -68,13 +70,15 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
 #pragma unroll
   for (int b = 0; b < NBQ; b++) best[b] = second[b] = zq(b) + dl;
 
-  const u32 nt = job.nt;
+  const u32 per = (job.nt + splits - 1) / splits;
+  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
+  const u32 nt = t1 - t0;
   if (nt) {
     // Train rows by buffer loads: the lane's row / byte offset is constant, the tile's offset the instruction's
     // immediate, the superstep's rides in the VGPR offset (one v_add per superstep; the range check is then on the
     // whole offset).  Rows past the end of the range read as zero and never count (see the last superstep).
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(tbytes + (size_t)job.t_off * 32), 0, nt * 32u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(tbytes + ((size_t)job.t_off + t0) * 32), 0, nt * 32u, 0x00020000);
     u32 voff = (32u * (c >> 3) + 4u * ((c >> 2) & 1u) + (c & 3u)) * 32u + g * 8u;
     auto load_super = [&](uint2 (&w)[4]) {
 #pragma unroll
@@ -250,15 +254,15 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
   asm volatile("" : "+s"(q0e));
 #pragma unroll
   for (int k = 0; k < (NBQ + 3) / 4; k++) asm volatile("" : "+v"(ppack[k]));
-  uint2* out = scratch + job.out_off;
-  const u32 sentinel = d_lim >= 256u ? KEY_INIT : (d_lim << IDX_BITS);
+  uint2* out = scratch + (size_t)split * split_stride + job.out_off;
+  const u32 sentinel = d_lim >= 256u ? KEY_INIT : ((d_lim << IDX_BITS) | t0);
   u32 mask_word = 0;
 #pragma unroll
   for (int b = 0; b < NBQ; b++) {
     const u32 bb = (u32)best[b], sb = (u32)second[b];
     const int zb = zq(b), init = zb + dl;
     const u32 i = bb & 15u;
-    const u32 row = 32u * ((bb >> 4) & 1023u) + 4u * h + (i & 3u) + 8u * (i >> 2);
+    const u32 row = t0 + 32u * ((bb >> 4) & 1023u) + 4u * h + (i & 3u) + 8u * (i >> 2);
     u32 kb = (int)bb < init ? (((((bb - (u32)zb) >> 14) & 255u) << IDX_BITS) | row) : sentinel;
     u32 ks = (int)(sb & ~16383u) < init ? ((((sb - (u32)zb) >> 14) & 255u) << IDX_BITS) : sentinel;
 #pragma unroll
@@ -304,10 +308,10 @@ __host__ __device__ inline Mfma16Tiling mfma16_tiling(u32 nq) {
 __host__ __device__ inline u32 mfma16_tiles(u32 nq) { return (2 * ((nq + 31) / 32) + MFMA16_NBQ - 1) / MFMA16_NBQ; }
 
 // One-wave workgroups; the grid of mfma_scan_kernel<*, 1>: tiles_per_job != 0: eight jobs side by side (one per XCD),
-// tile-major within them; else job-minor.
+// tile-major within them; else job-minor.  blockIdx.y = train split.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mfma16_scan_kernel(
     const u32x4* __restrict__ qbase, const u32x4* __restrict__ tbase, const Job* __restrict__ jobs, u32 n_jobs,
-    uint2* __restrict__ scratch, u32 tiles_per_job, u32 d_lim, AcceptMask acc) {
+    u32 splits, u32 split_stride, uint2* __restrict__ scratch, u32 tiles_per_job, u32 d_lim, AcceptMask acc) {
   const u32 lane = threadIdx.x & 63;
   __shared__ uint16_t lut[264];  // AcceptParams::min_second, for the epilogue (one-wave workgroup: no barrier needed beyond the wait)
   u32 j, t;
@@ -333,13 +337,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mf
   const char* q = (const char*)qbase;
   const char* tr = (const char*)tbase;
   switch (blocks) {
-    case 14: mfma16_scan_tile<14>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
-    case 12: mfma16_scan_tile<12>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
-    case 10: mfma16_scan_tile<10>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
-    case 8: mfma16_scan_tile<8>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
-    case 6: mfma16_scan_tile<6>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
-    case 4: mfma16_scan_tile<4>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
-    default: mfma16_scan_tile<2>(q, tr, job, q0, lane, scratch, d_lim, acc, lut); break;
+    case 14: mfma16_scan_tile<14>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
+    case 12: mfma16_scan_tile<12>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
+    case 10: mfma16_scan_tile<10>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
+    case 8: mfma16_scan_tile<8>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
+    case 6: mfma16_scan_tile<6>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
+    case 4: mfma16_scan_tile<4>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
+    default: mfma16_scan_tile<2>(q, tr, job, q0, lane, blockIdx.y, splits, split_stride, scratch, d_lim, acc, lut); break;
   }
 }
 

@@ -152,7 +152,7 @@ struct Mfma16Cost {
   double q16 = 0, q32 = 0, t = 0;
   size_t n = 0;
   u32 max_tiles = 0, min_tiles = 0xffffffffu;
-  void add(u32 nd) {
+  void add(u32 nd, u32 nt_rows = 0xffffffffu) {  // nt_rows: train rows a tile scans, when not the image (train splits)
     // a tile of nb blocks: 11.6 VALU instructions per block and superstep + 32 for the expansion of the train rows,
     // relative to the 14-block tile
     const Mfma16Tiling tg = mfma16_tiling(nd);
@@ -160,7 +160,7 @@ struct Mfma16Cost {
     // 32x32: full tiles of 256 queries, remainder tiles of 128 (- 3 %) and 64 (- 11 %), the last block left out when empty
     const u32 n64 = (nd + 63) >> 6, full = n64 / 4, rem = n64 & 3;
     q32 += full * 256.0 + ((rem & 2) ? 128 * 1.03 : 0.0) + ((rem & 1) ? 64 * 1.12 : 0.0) - (nd && ((nd - 1) & 63) < 32 ? 32.0 : 0.0);
-    t += (nd + 31) / 32 * 32;
+    t += (std::min(nd, nt_rows) + 31) / 32 * 32;
     n++;
     max_tiles = std::max(max_tiles, tg.tiles);
     min_tiles = std::min(min_tiles, tg.tiles);
@@ -416,13 +416,16 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
     while (s.jobs_per_wave < 4 && w / (2 * s.jobs_per_wave) >= 32768) s.jobs_per_wave *= 2;
     const int fj = (variant >> 20) & 0xf;  // knob bits 20-23: forced
     if (fj) s.jobs_per_wave = (u32)fj;
-    // the 16x16x128 kernel instead (batched forward scans: unsplit, 256-query tiles, step tags of 10 bits)
+  }
+  // the 16x16x128 kernel instead of the 256-query-tile 32x32x64 one (mfma16_scan.h; any number of train splits, step
+  // tags of 10 bits as there)
+  if (s.adaptive && s.mfma && s.rmax == 4) {
     Mfma16Stats st;
     if (m16) {
       st = *m16;
     } else {
       Mfma16Cost cost;
-      cost.add(max_nq);
+      cost.add(max_nq, per);
       st = cost.stats();
       st.uniform = false;
     }
@@ -486,7 +489,8 @@ int launch_scan(vsm_ctx* c, const void* qbase, const void* tbase, const Job* d_j
   hipLaunchKernelGGL((scan_kernel<RR, FF>), grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, \
                      split_stride, d_scratch, d_qlist)
   if (m16) {  // FP4 matrix-core scan on the 16x16x128 shape, 224 queries per wave
-    hipLaunchKernelGGL(mfma16_scan_kernel, grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, d_scratch, grouped, d_lim, acc);
+    hipLaunchKernelGGL(mfma16_scan_kernel, grid, block, 0, c->stream, q, t, d_jobs, (u32)n_jobs, sh.splits, split_stride, d_scratch, grouped,
+                       d_lim, acc);
   } else if (sh.adaptive && sh.mfma) {  // FP4 matrix-core scan on the 32x32x64 shape, 32 * NB queries per wave
     if (sh.rmax == 4) VSM_LAUNCH_M(8, 1);
     else if (sh.rmax == 2) VSM_LAUNCH_M(4, 1);
