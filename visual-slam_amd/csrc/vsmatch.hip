@@ -433,6 +433,9 @@ ScanShape choose_shape(u64 n_jobs, u32 max_nq, u32 max_nt, int variant, const u3
     if (s.mfma16) {
       s.tiles = st.max_tiles;
       s.uniform = st.uniform;
+      // (no runs of jobs in this kernel: built and measured -- tools/history/mfma16_scan_with_runs_of_jobs.h: the loop
+      // costs 100 spilled registers around every job; runs of four then gain 4 % over runs of one of the SAME code, which
+      // is 6 % slower than the kernel without the loop: 14.87 against 15.5 T relative to the 32x32 kernel's 14.3 / 14.55)
       s.jobs_per_wave = 1;
     }
   }
