@@ -51,6 +51,43 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
   asm volatile("" : "+s"(m88), "+v"(c11), "+s"(m44), "+s"(m22), "+s"(m11));
   auto expand_train = [&](u32 w) { return expand_train_zr(w, m88, c11, m44, m22, m11); };
 
+  // The split's share of the train range and its first rows, before anything else: the loads are in flight while the
+  // queries are loaded and expanded.  Train rows by buffer loads: the lane's row / byte offset is constant, the tile's
+  // offset the instruction's immediate, the superstep's rides in the VGPR offset (one v_add per superstep; the range
+  // check is then on the whole offset).  Rows past the end of the range read as zero and never count (see the tail).
+  const u32 per = (job.nt + splits - 1) / splits;
+  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
+  const u32 nt = t1 - t0;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(tbytes + ((size_t)job.t_off + t0) * 32), 0, nt * 32u, 0x00020000);
+  u32 voff = (32u * (c >> 3) + 4u * ((c >> 2) & 1u) + (c & 3u)) * 32u + g * 8u;
+  auto load_super = [&](uint2 (&w)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 256u * t, 0, 0);
+      w[t] = make_uint2((u32)v[0], (u32)v[1]);
+    }
+    voff += 2048u;
+  };
+  uint2 w[4], wn[4];
+  const u32 sfull = nt / 64, left = nt - sfull * 64u;  // full supersteps; rows of the tail (below)
+  // the tail's rows: loaded behind the first block of the last full superstep, into the registers of the
+  // prefetch that superstep does not need
+  const u32 voff_tail = (16u * (c >> 3) + 4u * ((c >> 2) & 1u) + (c & 3u)) * 32u + g * 8u + sfull * 2048u;
+  auto load_tail = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // k = 2 * half-step + tile
+      const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_tail + 1024u * (k >> 1) + 256u * (k & 1), 0, 0);
+      wn[k] = make_uint2((u32)v[0], (u32)v[1]);
+    }
+  };
+  if (sfull) {
+    load_super(w);
+    load_super(wn);
+  } else {
+    load_tail();
+  }
+
   i32x8 B[NBQ][2];
   u32 ppack[(NBQ + 3) / 4] = {};  // P of mfma_scan.h (CODES 1) per block, see zq
   auto zq = [&](int b) { return ZR_BASE - (int)(((ppack[b >> 2] >> (8 * (b & 3))) & 255u) << 14); };
@@ -70,24 +107,7 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
 #pragma unroll
   for (int b = 0; b < NBQ; b++) best[b] = second[b] = zq(b) + dl;
 
-  const u32 per = (job.nt + splits - 1) / splits;
-  const u32 t0 = min(split * per, job.nt), t1 = min(t0 + per, job.nt);
-  const u32 nt = t1 - t0;
   if (nt) {
-    // Train rows by buffer loads: the lane's row / byte offset is constant, the tile's offset the instruction's
-    // immediate, the superstep's rides in the VGPR offset (one v_add per superstep; the range check is then on the
-    // whole offset).  Rows past the end of the range read as zero and never count (see the last superstep).
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(tbytes + ((size_t)job.t_off + t0) * 32), 0, nt * 32u, 0x00020000);
-    u32 voff = (32u * (c >> 3) + 4u * ((c >> 2) & 1u) + (c & 3u)) * 32u + g * 8u;
-    auto load_super = [&](uint2 (&w)[4]) {
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 256u * t, 0, 0);
-        w[t] = make_uint2((u32)v[0], (u32)v[1]);
-      }
-      voff += 2048u;
-    };
     auto expand_super = [&](const uint2 (&w)[4], i32x8 (&X)[4][2]) {
 #pragma unroll
       for (int t = 0; t < 4; t++) {
@@ -121,23 +141,9 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
       const int m3 = min3i(x[9], x[10], x[11]), m4 = min3i(x[12], x[13], x[14]);
       return min(min3i(m0, m1, m2), min3i(m3, m4, x[15]));
     };
-    uint2 w[4], wn[4];
     i32x8 A[4][2], An[4][2];
-    const u32 sfull = nt / 64, left = nt - sfull * 64u;  // full supersteps; rows of the tail (below)
-    // the tail's rows: loaded behind the first block of the last full superstep, into the registers of the
-    // prefetch that superstep does not need
-    const u32 voff_tail = (16u * (c >> 3) + 4u * ((c >> 2) & 1u) + (c & 3u)) * 32u + g * 8u + sfull * 2048u;
-    auto load_tail = [&]() {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {  // k = 2 * half-step + tile
-        const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff_tail + 1024u * (k >> 1) + 256u * (k & 1), 0, 0);
-        wn[k] = make_uint2((u32)v[0], (u32)v[1]);
-      }
-    };
     int step16 = (int)(16u * (g >> 1));  // 16 x the 32-row step this lane's group belongs to: 2 S + (g >> 1)
     if (sfull) {
-      load_super(w);
-      load_super(wn);
       expand_super(w, A);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
@@ -191,8 +197,6 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
       };
       for (u32 S = 0; S + 1 < sfull; S++) run_super(std::false_type{});
       run_super(std::true_type{});
-    } else {
-      load_tail();
     }
     // The tail: the `left` < 64 rows behind the last full superstep, in HALF-STEPS of 32 rows, two tiles each: tile
     // tau's row 4 g + j is row 8 (2 (g >> 1) + tau) + 4 (g & 1) + j of the half-step, so that a lane's eight rows are
@@ -328,8 +332,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void mf
   const Job job = jobs[j];
   const Mfma16Tiling tl = mfma16_tiling(job.nq);
   if (t >= tl.tiles) return;
-  if (acc.mask) {
-    for (u32 k = lane; k < 257; k += 64) lut[k] = acc.lut[k];
+  if (acc.mask) {  // (the five loads of a lane issued together)
+    uint16_t v[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = acc.lut[min(lane + 64 * k, 256u)];
+#pragma unroll
+    for (int k = 0; k < 5; k++) lut[min(lane + 64 * k, 256u)] = v[k];
     __syncthreads();
   }
   const u32 blocks = t < tl.big_tiles ? tl.small + 2 : tl.small;
