@@ -91,16 +91,32 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
   i32x8 B[NBQ][2];
   u32 ppack[(NBQ + 3) / 4] = {};  // P of mfma_scan.h (CODES 1) per block, see zq
   auto zq = [&](int b) { return ZR_BASE - (int)(((ppack[b >> 2] >> (8 * (b & 3))) & 255u) << 14); };
+  {
+    // query codes (expand_query_zr) with the masks in registers: a shift and one v_and_or_b32 per register
+    u32 q22 = 0x22222222u, q44 = 0x44444444u;
+    asm volatile("" : "+v"(q22), "+v"(q44));
+    auto expand_query = [&](u32 w) {
+      i32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      v[0] = (int)((~w & m88) | q22);
+      v[1] = (int)(((w << 1) & m88) | c11);
+      v[2] = (int)(((w << 2) & m88) | q22);
+      v[3] = (int)(((w << 3) & m88) | q44);
+      return v;
+    };
 #pragma unroll
-  for (int b = 0; b < NBQ; b++) {
-    const u32 qi = min(q0 + b * 16 + c, job.nq - 1);
-    const uint2 w = *(const uint2*)(qbytes + (size_t)(job.q_off + qi) * 32 + g * 8);
-    B[b][0] = expand_query_zr(w.x);
-    B[b][1] = expand_query_zr(w.y);
-    int ph = __popc(w.x & 0x77777777u) + __popc(w.y & 0x77777777u);
-    ph += __shfl_xor(ph, 16);
-    ph += __shfl_xor(ph, 32);
-    ppack[b >> 2] |= (u32)ph << (8 * (b & 3));
+    for (int b = 0; b < NBQ; b++) {
+      const u32 qi = min(q0 + b * 16 + c, job.nq - 1);
+      const uint2 w = *(const uint2*)(qbytes + (size_t)(job.q_off + qi) * 32 + g * 8);
+      B[b][0] = expand_query(w.x);
+      B[b][1] = expand_query(w.y);
+      // this lane's share of P (at most 48 of 192): the four lanes of a query are added up below, four blocks at once
+      ppack[b >> 2] |= (u32)(__popc(w.x & 0x77777777u) + __popc(w.y & 0x77777777u)) << (8 * (b & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < (NBQ + 3) / 4; k++) {
+      ppack[k] += (u32)__shfl_xor((int)ppack[k], 16);
+      ppack[k] += (u32)__shfl_xor((int)ppack[k], 32);
+    }
   }
   const int dl = (int)(min(d_lim, 256u) << 14);  // start value of (best, second) above zq
   int best[NBQ], second[NBQ];
