@@ -129,8 +129,12 @@ for d in ("pop_trace", "pop_sq", "pop_fetch", "pop_write"):
             pc["sustained_clock_ghz"] = sum(clk) / len(clk)
 if pc:
     if "SQ_ACTIVE_INST_VALU" in pc and "GRBM_GUI_ACTIVE" in pc:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs (MI355X_MICROARCH.md): x4 / SIMDs / cycles per XCD
-        pc["valu_busy_frac"] = pc["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / (pc["GRBM_GUI_ACTIVE"] / XCDS)
+        # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md), here one per VALU instruction (= SQ_INSTS_VALU):
+        # x4 / SIMDs / cycles per XCD = nominal four-cycle VALU passes per SIMD cycle.  Above 1: gfx950 issues the
+        # scan's v_xor / v_bcnt in 2.3-4.6 cycles per wave64 instruction, not 4 (profiles/r01/valu_rate2_set1_opcodes.txt)
+        # -- the utilisation against the MEASURED issue rate is bench.py's popcount_path.roofline.frac (0.90).
+        pc["valu_nominal_passes_per_simd_cycle"] = pc["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / (pc["GRBM_GUI_ACTIVE"] / XCDS)
+        pc["valu_instructions_per_simd_cycle"] = pc["SQ_INSTS_VALU"] / SIMDS / (pc["GRBM_GUI_ACTIVE"] / XCDS)
     if "FETCH_SIZE" in pc and "WRITE_SIZE" in pc:
         pc["hbm_bytes_per_pair"] = (2 * pc["FETCH_SIZE"] + pc["WRITE_SIZE"]) * 1024 / pairs
     if "SQ_INSTS_VALU" in pc:
