@@ -5,11 +5,14 @@ host's core count and CPU model)."""
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r02", "bench_round2_final.json")) as f:
+@pytest.mark.parametrize("rel", ["r02/bench_round2_final.json", "r03/bench_round3_final.json"])
+def test_committed_bench_line_has_the_contract_fields(rel):
+    with open(os.path.join(ROOT, "profiles", *rel.split("/"))) as f:
         d = json.loads(f.readline())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -39,3 +42,9 @@ def test_committed_bench_line_has_the_contract_fields():
     assert c["kind"] in ("reference", "port") and c["gpu_lists_bit_exact"] is True
     assert d["value"] > 100 * c["value"]
     assert d["extra"]["stereo_1500x1500"]["latency_ms_host_to_host"] < 0.040
+    if rel.startswith("r03"):  # the counters belong to the running code; which kernel the line is about
+        assert r["counters_stale"] is False and "frac_of_peak_at_sustained_clock" in r
+        assert "16x16x128" in r["kernel"] and r["frac"] > 0.76
+        assert d["extra"]["nn2_1Mx1M"]["roofline_frac"] > 0.8
+        x = d["real_like"]["matrix_core"]  # consumer kernels: the step outside the scans
+        assert x["total_ms"] < 1.10 * (x["forward_scan_ms"] + x["backward_scan_ms"])
