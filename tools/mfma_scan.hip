@@ -277,7 +277,7 @@ int main(int argc, char** argv) {
 
   struct V { const char* name; int fmt, nb; };  // fmt 4: key tracking with the skip test, 14: distance-only tracking, 24: group tracking
 #ifdef VSM_PRODUCT
-  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16 product", 104, 1}, {"shipped NB8", 24, 8}, {"16x16 product", 104, 1}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12}, {"16x16 v3, 208-query tiles", 84, 13},
+  const V vs[] = {{"shipped NB8", 24, 8}, {"16x16 product", 104, 14}, {"shipped NB8", 24, 8}, {"16x16 product", 104, 14}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12}, {"16x16 v3, 208-query tiles", 84, 13},
                   {"shipped NB8", 24, 8}, {"16x16 v3, 224-query tiles", 84, 14}, {"16x16 v3, 192-query tiles", 84, 12},
                   {"16x16x128, 192-query tiles", 74, 12}, {"16x16x128, 128-query tiles", 74, 8},
                   {"16x16x128, 160-query tiles", 74, 10}, {"16x16x128, 224-query tiles", 74, 14},
