@@ -532,12 +532,14 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
                        const AcceptParams& prm, u64* d_out_offsets, int2* d_out_pairs,
                        size_t cap_pairs, size_t* out_total) {
   // `misc`: [u64 running total][u64 comparisons, full/forward scans][u64 comparisons,
-  //          pruned backward scans][u32 bad-pair flag]
-  VSM_TRY(c->misc.reserve(64));
+  //          pruned backward scans][u32 bad-pair flag] ... from byte 128: nominate_kernel's COMPS_SLOTS counters
+  constexpr size_t MISC_BYTES = 128 + COMPS_SLOTS * COMPS_SLOT_STRIDE * sizeof(u64);
+  VSM_TRY(c->misc.reserve(MISC_BYTES));
   u64* d_running = (u64*)c->misc.p;
   u64* d_comps = d_running + 1;
   u32* d_bad = (u32*)(d_running + 3);
-  HIP_TRY(hipMemsetAsync(c->misc.p, 0, 32, c->stream));
+  u64* d_slots = d_running + 16;
+  HIP_TRY(hipMemsetAsync(c->misc.p, 0, MISC_BYTES, c->stream));
   if (n_pairs == 0) {
     HIP_TRY(hipMemsetAsync(d_out_offsets, 0, sizeof(u64), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -606,12 +608,12 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     HIP_TRY(hipGetLastError());
     if (prune) {
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs, n, sh, (u32)split_stride, d_scratch, 0, nullptr, d_lim, acc));
-      hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, prm,
-                         stride, (u32*)c->qlist.p, (uint2*)c->flist.p, d_comps + 1, (const u32*)acc.mask);
+      hipLaunchKernelGGL(nominate_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, n, d_scratch, prm,
+                         stride, (u32*)c->qlist.p, (uint2*)c->flist.p, d_slots, (const u32*)acc.mask);
       HIP_TRY(hipGetLastError());
       VSM_TRY(launch_scan(c, d_desc, d_desc, d_jobs + n, n, shb, (u32)split_stride, d_scratch, 0,
                           (const u32*)c->qlist.p, d_lim));
-      hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch,
+      hipLaunchKernelGGL(count_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, n, d_scratch,
                          (const uint2*)c->flist.p, stride, prm, d_counts, desc,
                          (sh.mfma ? 1u : 0u) | (shb.mfma ? 2u : 0u), gmin);
     } else {
@@ -628,7 +630,7 @@ int match_pairs_device(vsm_ctx* c, const void* d_desc, const u32* d_img_off, u32
     }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, c->stream, d_counts, n,
-                       d_out_offsets, first, d_running);
+                       d_out_offsets, first, d_running, prune ? d_slots : nullptr, d_comps + 1);
     HIP_TRY(hipGetLastError());
     if (prune)
       hipLaunchKernelGGL(fill_list_kernel, dim3(n), dim3(256), 0, c->stream, d_jobs, d_scratch, d_out_offsets, first,

@@ -461,6 +461,11 @@ __device__ __forceinline__ void load_lut(uint16_t* lut, const AcceptParams& prm)
   for (u32 k = threadIdx.x; k < 257; k += blockDim.x) lut[k] = prm.min_second[k];
   __syncthreads();
 }
+// the same for the 256-thread consumer kernels, without the barrier (the caller has one before its first look-up)
+__device__ __forceinline__ void load_lut_256(uint16_t* lut, const AcceptParams& prm) {
+  lut[threadIdx.x] = prm.min_second[threadIdx.x];
+  if (threadIdx.x == 0) lut[256] = prm.min_second[256];
+}
 
 // Unpruned paths (one stereo pair; batches whose scans are split or whose images exceed the
 // nominate bitmap): folds the partial results of the train splits into split 0 like
@@ -514,12 +519,23 @@ __global__ __launch_bounds__(256) void count_kernel(const Job* __restrict__ jobs
   if (threadIdx.x == 0) counts[blockIdx.x] = total;
 }
 
+constexpr u32 COMPS_SLOTS = 64, COMPS_SLOT_STRIDE = 16;  // nominate_kernel's comparison counters; stride in u64: 128 bytes
+
 // Exclusive scan of the chunk's counts into global u64 offsets, continuing from
 // *running (the total of the previous chunks); writes offsets[first + k] and
-// finally *running = offsets[first + n].  Single 1024-thread workgroup.
+// finally *running = offsets[first + n].  Single 1024-thread workgroup.  With `slots`: also moves what
+// nominate_kernel added to its COMPS_SLOTS counters into *comps and clears them.
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict__ counts, u32 n,
                                                            u64* __restrict__ offsets, u64 first,
-                                                           u64* __restrict__ running) {
+                                                           u64* __restrict__ running, u64* __restrict__ slots,
+                                                           u64* __restrict__ comps) {
+  if (slots && threadIdx.x < 64) {
+    static_assert(COMPS_SLOTS == 64, "one slot per lane of the first wave");
+    u64 v = slots[COMPS_SLOT_STRIDE * threadIdx.x];
+    slots[COMPS_SLOT_STRIDE * threadIdx.x] = 0;
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if (threadIdx.x == 0) *comps += v;
+  }
   // 4096 counts per round: every thread takes four consecutive ones (coalesced 16-byte loads).
   __shared__ u64 wave_sum[16];
   __shared__ u64 carry;
@@ -753,7 +769,7 @@ __global__ void plan_pairs_kernel(const uint2* __restrict__ pairs, u32 n_pairs,
 // computed.  Needs stride <= NOMINATE_MAX_STRIDE (LDS bitmap) and splits == 1.
 constexpr u32 NOMINATE_MAX_STRIDE = 65536;
 constexpr u32 NOMINATE_LDS_LIST = 2048;
-__global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
+__global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs, u32 n_pairs,
                                                        uint2* __restrict__ scratch,
                                                        AcceptParams prm, u32 stride,
                                                        u32* __restrict__ qlist,
@@ -767,10 +783,12 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   // back from global memory right after writing them cost a round trip per workgroup (215 us per
   // 32768 sparse pairs against 80 us)
   __shared__ u32 slist[NOMINATE_LDS_LIST];
-  load_lut(lut, prm);
+  // (n_pairs is an argument: with gridDim.x the index of the backward job, and so the job, came through vector loads --
+  // a workgroup of these kernels is a chain of dependent loads and little else, every link ~1.5 us under load)
+  if (!accmask) load_lut_256(lut, prm);
   const u32 p = blockIdx.x;
   Job f = jobs[p];
-  Job b = jobs[gridDim.x + p];
+  Job b = jobs[n_pairs + p];
   const u32 n2 = b.nq, words = (n2 + 31) / 32;
   for (u32 w = threadIdx.x; w < words; w += 256) bitmap[w] = 0;
   __syncthreads();
@@ -828,12 +846,21 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
   __syncthreads();  // the list is read below by other threads
   // mark the columns of the listed rows; the list entry takes the key along, so that the consumer kernels
   // read (row, column, distance) in one coalesced 8-byte load instead of the row's result at a random place
-  for (u32 k = threadIdx.x; k < acc; k += 256) {
-    const u32 i = k < NOMINATE_LDS_LIST ? slist[k] : list[k].x;
-    const u32 key = scratch[f.out_off + i].x;
-    const u32 j = key & IDX_MASK;
-    atomicOr(&bitmap[j >> 5], 1u << (j & 31));
-    list[k] = make_uint2(i, key);
+  // (two entries per thread and turn, both keys requested before either is used)
+  for (u32 k0 = threadIdx.x; k0 < acc; k0 += 512) {
+    const u32 k1 = k0 + 256;
+    const bool two = k1 < acc;
+    const u32 i0 = k0 < NOMINATE_LDS_LIST ? slist[k0] : list[k0].x;
+    const u32 i1 = !two ? i0 : k1 < NOMINATE_LDS_LIST ? slist[k1] : list[k1].x;
+    const u32 key0 = scratch[f.out_off + i0].x;
+    const u32 key1 = scratch[f.out_off + i1].x;
+    const u32 j0 = key0 & IDX_MASK, j1 = key1 & IDX_MASK;
+    atomicOr(&bitmap[j0 >> 5], 1u << (j0 & 31));
+    list[k0] = make_uint2(i0, key0);
+    if (two) {
+      atomicOr(&bitmap[j1 >> 5], 1u << (j1 & 31));
+      list[k1] = make_uint2(i1, key1);
+    }
   }
   __syncthreads();
   u32 done = 0;
@@ -852,8 +879,11 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
     jobs[p] = f;
     b.nq = done;
     b.qlist_off = p * stride;
-    jobs[gridDim.x + p] = b;
-    if (done && b.nt) atomicAdd((unsigned long long*)comps, (unsigned long long)done * b.nt);
+    jobs[n_pairs + p] = b;
+    // one of COMPS_SLOTS counters, 128 bytes apart (scan_counts_kernel sums them): adds of every workgroup to ONE
+    // word are served one after the other, ~11 ns each -- 19900 pairs with nominated columns held this kernel
+    // for 220 of its 268 us
+    if (done && b.nt) atomicAdd((unsigned long long*)comps + COMPS_SLOT_STRIDE * (p % COMPS_SLOTS), (unsigned long long)done * b.nt);
   }
 }
 
@@ -871,42 +901,54 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs,
 // per listed row one random 8-byte read (the backward result) and two table bytes instead of the six random reads of
 // the rounds before (forward result in three kernels, backward result twice): nominate + count_list + fill_list
 // 0.91 -> 0.64 ms on the real-like batch (fill_list 253 -> 27 us, count_list 390 -> 348 us).
-__global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__ jobs,
+__global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__ jobs, u32 n_pairs,
                                                          uint2* __restrict__ scratch,
                                                          const uint2* __restrict__ flist, u32 stride,
                                                          AcceptParams prm, u32* __restrict__ counts,
                                                          const u32x4* __restrict__ desc, u32 refine,
                                                          const uint8_t* __restrict__ gmin) {
-  // The results the table does not settle (~5 % on a dense batch) go to a queue in LDS and are refined by TEAMS of 16
-  // lanes, one group row per lane (as merge_refine_wide_kernel does): with refine_second called where it is needed,
+  // The results the table does not settle (~5 % on a dense batch) go to a queue in LDS and are refined by TEAMS of 8
+  // lanes, two group rows per lane (as merge_refine_wide_kernel does): with refine_second called where it is needed,
   // nearly every wave had a lane that needed it and ran its sixteen-row loop for that lane alone -- 890 VALU
   // instructions per wave, most of them in these loops (rocprofv3 SQ_INSTS_VALU, real-like batch).
-  // (Eight / two entries per thread with their loads issued together were measured too: 379 / 360 us against 348.)
+  // What is left is a chain of dependent loads (a workgroup's ~250 VALU instructions per turn are nothing beside
+  // it), so the chain is kept short: both jobs through scalar loads (n_pairs is an argument; with gridDim.x the
+  // backward job came through two vector loads), the backward result as ONE 8-byte load (the accept test's
+  // short-circuit had split it in two dependent ones), both table bytes requested WITH the backward result (the
+  // backward one sits at row i if the entry is a match at all) and the next turn's list entry requested a turn ahead:
+  // per turn list -> backward result -> its second word -> table byte -> descriptors became
+  // {backward result, table bytes, next entry} -> descriptors.
+  // (Eight / two entries per thread with their loads issued together were measured too, before that: 379 / 360 us
+  // against 348.)
   __shared__ uint16_t lut[260];
   __shared__ u32 wave_cnt[4];
   __shared__ u32 n_tasks;
   __shared__ u32 task_q[512], task_t[512], task_nt[512], task_key[512], task_who[512];  // who: thread << 1 | direction
   __shared__ u32 reject[256];
-  load_lut(lut, prm);
-  const Job f = jobs[blockIdx.x], b = jobs[gridDim.x + blockIdx.x];
+  load_lut_256(lut, prm);
+  const Job f = jobs[blockIdx.x], b = jobs[n_pairs + blockIdx.x];
   const uint2* list = flist + (size_t)blockIdx.x * stride;
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool table = gmin != nullptr;
   u32 done = 0;
+  uint2 e_next = threadIdx.x < f.pad1 ? list[threadIdx.x] : make_uint2(0u, 0u);
   for (u32 base = 0; base < f.pad1; base += 256) {
     if (threadIdx.x == 0) n_tasks = 0;
     reject[threadIdx.x] = 0;
-    __syncthreads();
+    __syncthreads();  // (and the accept table is there)
     const u32 k = base + threadIdx.x;
-    u32 i = 0, j = 0;
+    const uint2 e = e_next;
+    const u32 i = e.x, j = e.y & IDX_MASK;
     bool hit = false;
     if (k < f.pad1) {
-      const uint2 e = list[k];
-      i = e.x;
-      j = e.y & IDX_MASK;
-      const uint2 vb = scratch[b.out_off + j];
+      const unsigned long long raw = *reinterpret_cast<const unsigned long long*>(scratch + b.out_off + j);
+      const u32 gf = table ? (u32)gmin[f.t_off + j] : 0u, gb = table ? (u32)gmin[b.t_off + i] : 0u;
+      if (k + 256 < f.pad1) e_next = list[k + 256];
+      const uint2 vb = make_uint2((u32)raw, (u32)(raw >> 32));
       u32 back;
       hit = accepted(vb, lut, prm.threshold, back) && back == i;
-      if (hit && (refine & 1u) && !second_certified(gmin, f.t_off, make_uint2(e.y, 0u), lut)) {
+      const u32 df = min(e.y >> IDX_BITS, 256u), db = min(vb.x >> IDX_BITS, 256u);
+      if (hit && (refine & 1u) && !(table && gf >= (u32)lut[df] + df)) {  // second_certified, forward
         const u32 t = atomicAdd(&n_tasks, 1u);
         task_q[t] = f.q_off + i;
         task_t[t] = f.t_off;
@@ -914,7 +956,7 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
         task_key[t] = e.y;
         task_who[t] = threadIdx.x << 1;
       }
-      if (hit && (refine & 2u) && !second_certified(gmin, b.t_off, vb, lut)) {
+      if (hit && (refine & 2u) && !(table && gb >= (u32)lut[db] + db)) {  // backward: its best is row i
         const u32 t = atomicAdd(&n_tasks, 1u);
         task_q[t] = b.q_off + j;
         task_t[t] = b.t_off;
@@ -924,21 +966,26 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
       }
     }
     __syncthreads();
-    // a team per task: the fifteen group mates of the best (refine_second: rows b0 + (l & 3) + 8 (l >> 2) of the
-    // best's 32-row step, unsplit scan); a closer one than the accept test's least second best rejects the entry
-    // (the stored second best passed the test already)
-    const u32 nt_ = n_tasks, team = threadIdx.x >> 4, l = threadIdx.x & 15;
-    for (u32 t = team; t < nt_; t += 16) {
+    // a team per task: the fifteen group mates of the best (refine_second: rows b0 + (r & 3) + 8 (r >> 2) of the
+    // best's 32-row step, r = 0 .. 15, unsplit scan), lane l of the team takes r = l and l + 8; a closer one than
+    // the accept test's least second best rejects the entry (the stored second best passed the test already)
+    const u32 nt_ = n_tasks, team = threadIdx.x >> 3, l = threadIdx.x & 7;
+    for (u32 t = team; t < nt_; t += 32) {
       const u32 key = task_key[t], idx = key & IDX_MASK, d = key >> IDX_BITS, ntr = task_nt[t];
-      const u32 r = (idx & ~31u) + (idx & 4u) + (l & 3u) + 8u * (l >> 2);
+      const u32 r0 = (idx & ~31u) + (idx & 4u) + (l & 3u) + 8u * (l >> 2), r1 = r0 + 16u;
       const u32x4* dq = desc + 2 * (size_t)task_q[t];
-      const u32x4* dt = desc + 2 * ((size_t)task_t[t] + min(r, ntr - 1));
-      const u32x4 qa = dq[0], qb = dq[1], ta = dt[0], tb = dt[1];
-      u32 dr = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-               __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-      dr = (r < ntr && r != idx) ? dr : 0x1ffu;
+      const u32x4* d0 = desc + 2 * ((size_t)task_t[t] + min(r0, ntr - 1));
+      const u32x4* d1 = desc + 2 * ((size_t)task_t[t] + min(r1, ntr - 1));
+      const u32x4 qa = dq[0], qb = dq[1], ta = d0[0], tb = d0[1], ua = d1[0], ub = d1[1];
+      u32 dr0 = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+      u32 dr1 = __popc(qa.x ^ ua.x) + __popc(qa.y ^ ua.y) + __popc(qa.z ^ ua.z) + __popc(qa.w ^ ua.w) +
+                __popc(qb.x ^ ub.x) + __popc(qb.y ^ ub.y) + __popc(qb.z ^ ub.z) + __popc(qb.w ^ ub.w);
+      dr0 = (r0 < ntr && r0 != idx) ? dr0 : 0x1ffu;
+      dr1 = (r1 < ntr && r1 != idx) ? dr1 : 0x1ffu;
+      u32 dr = min(dr0, dr1);
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) dr = min(dr, (u32)__shfl_xor((int)dr, o, 16));
+      for (int o = 1; o < 8; o <<= 1) dr = min(dr, (u32)__shfl_xor((int)dr, o, 8));
       if (l == 0 && dr < (u32)lut[min(d, 256u)]) reject[task_who[t] >> 1] = 1;
     }
     __syncthreads();
