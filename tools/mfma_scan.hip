@@ -290,7 +290,12 @@ int main(int argc, char** argv) {
   const V vs[] = {{"mfma keys NB8", 4, 8}, {"mfma keys NB4", 4, 4}, {"mfma dist NB8", 14, 8}, {"mfma dist NB4", 14, 4}, {"mfma dist NB2", 14, 2},
                   {"mfma group NB8", 24, 8}, {"mfma group NB4", 24, 4}, {"mfma group NB2", 24, 2}};
 #endif
+  // VSM_FMT=104: only the variants of that format; VSM_LDS_PAD=36864: dynamic LDS per workgroup of the 16x16 product
+  // kernel, so that four one-wave workgroups fit a CU -- ONE wave per SIMD: what a wave does to the MFMA pipe alone
+  const int only_fmt = getenv("VSM_FMT") ? atoi(getenv("VSM_FMT")) : 0;
+  const u32 lds_pad = getenv("VSM_LDS_PAD") ? (u32)atoi(getenv("VSM_LDS_PAD")) : 0u;
   for (const V& v : vs) {
+    if (only_fmt && v.fmt != only_fmt) continue;
     float tm = 1e30f;
     const u32 tiles = adaptive_tiles(N, v.fmt == 74 ? 4 : v.nb / 2), groups = (n_jobs + 7) / 8;
     for (int rep = 0; rep < 3; rep++) {
@@ -317,7 +322,7 @@ int main(int argc, char** argv) {
       } else
       if (v.fmt == 104) {
         const u32 t16 = mfma16_tiles(N);
-        mfma16_scan_kernel<<<dim3(groups * 8 * t16), blk>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, t16, d_lim, AcceptMask{nullptr, 0, nullptr});
+        mfma16_scan_kernel<<<dim3(groups * 8 * t16), blk, lds_pad>>>((const u32x4*)db, (const u32x4*)db, d_jobs, n_jobs, 1u, (u32)n_scr, scr, t16, d_lim, AcceptMask{nullptr, 0, nullptr});
       } else
       if (v.fmt == 84) {
         const u32 t16 = (N + 16 * v.nb - 1) / (16 * v.nb);
