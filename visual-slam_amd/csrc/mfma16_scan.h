@@ -138,16 +138,16 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
       for (int j = 0; j < 4; j++) zero[t][j] = __int_as_float(ZR_START + 4 * t + j);
       asm volatile("" : "+v"(zero[t]));
     }
-    // the eight MFMAs of (superstep operands X, query block b): the k halves of a tile two MFMAs apart
+    // the eight MFMAs of (superstep operands X, query block b): the k halves of a tile BACK TO BACK -- the second
+    // takes the first's result as its accumulator straight from the pipe: +2.3 to +3.5 % over the two halves two
+    // MFMAs apart (as first written, for the latency of the dependence), +2 % over four apart, same box, 1333 ... 2500
+    // descriptors per image (profiles/r03/scan16_mfma_order.txt)
     auto block_mfmas = [&](const i32x8 (&X)[4][2], int b, const f32x4 (&Z)[4], f32x4 (&R)[4]) {
-      R[0] = mfma16_step(X[0][0], B[b][0], Z[0]);
-      R[1] = mfma16_step(X[1][0], B[b][0], Z[1]);
-      R[0] = mfma16_step(X[0][1], B[b][1], R[0]);
-      R[1] = mfma16_step(X[1][1], B[b][1], R[1]);
-      R[2] = mfma16_step(X[2][0], B[b][0], Z[2]);
-      R[3] = mfma16_step(X[3][0], B[b][0], Z[3]);
-      R[2] = mfma16_step(X[2][1], B[b][1], R[2]);
-      R[3] = mfma16_step(X[3][1], B[b][1], R[3]);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        R[t] = mfma16_step(X[t][0], B[b][0], Z[t]);
+        R[t] = mfma16_step(X[t][1], B[b][1], R[t]);
+      }
     };
     auto med3 = [](int p, int q, int r) {
       return __float_as_int(__builtin_amdgcn_fmed3f(__int_as_float(p), __int_as_float(q), __int_as_float(r)));
@@ -193,7 +193,9 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
           second[b] = med3(best[b], m, second[b]);
           best[b] = min(best[b], m | step16);
 #pragma unroll
-          for (int n = 0; n < 8; n++) {
+          for (int n = 0; n < 8; n++) {  // (one MFMA, two others; with the last three MFMAs one apart instead, or the
+            // first three, or every other one: the same within the run-to-run spread; the pairs of a tile ADJACENT,
+            // two MFMAs then four others: the gain of the back-to-back order is gone)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
           }
@@ -240,8 +242,8 @@ __device__ __forceinline__ void mfma16_scan_tile(const char* __restrict__ qbytes
         const int st16 = (int)(16u * (2u * sfull + hs));
         auto half_mfmas = [&](int b, f32x4 (&R)[2]) {
           R[0] = mfma16_step(T[0][0], B[b][0], zs[0]);
-          R[1] = mfma16_step(T[1][0], B[b][0], zs[1]);
           R[0] = mfma16_step(T[0][1], B[b][1], R[0]);
+          R[1] = mfma16_step(T[1][0], B[b][0], zs[1]);
           R[1] = mfma16_step(T[1][1], B[b][1], R[1]);
         };
         f32x4 E[2];

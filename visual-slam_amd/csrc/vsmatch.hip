@@ -139,11 +139,12 @@ constexpr u32 LONG_SCAN_WAVES = 98304;              // long scans are split unti
 // The 16x16x128 forward scan (mfma16_scan.h) on a set of images: tiles per image and an estimate of its time against
 // the 32x32x64 scan's, both of the form  (padded queries, weighted by tile size) x (padded train rows + a fixed cost per
 // tile and block in rows).  Fitted to tools/mfma_scan.hip on one box (profiles/r03/scan16_product_by_size.txt): per
-// padded comparison the 16x16 scan takes 0.867 of the time, its fixed cost is 320 rows per block against 115 (two
+// padded comparison the 16x16 scan took 0.867 of the time, its fixed cost is 320 rows per block against 115 (two
 // merges of four lanes per result, the tail behind the pipelined loop); against the 32x32 kernel WITH its runs of jobs
-// (all-pairs lists through the library: tools/m16_rule_probe.py, profiles/r03/m16_rule_probe.txt) 400 rows -- it wins
-// from ~1900 train rows per image up: + 3 % at 2000 and 2500 in batches of 8128 pairs, + 6.5 to + 7.8 % on the bench's
-// 32768-pair launches, - 5 % at 1400-1600, - 15 % at 500.
+// (all-pairs lists through the library: tools/m16_rule_probe.py, profiles/r03/m16_rule_probe.txt) 400 rows; with the
+// k halves of a tile issued back to back (mfma16_scan.h: + 3 %) 0.843 -- it wins from ~1750 train rows per image up:
+// + 8 % at 2000 and + 10 % at 2500 in batches of 8128 pairs (forward kernel), + 9 to + 11 % on the bench's 32768-pair
+// launches, a tie at 1400, - 3 % at 1200 and 1600, - 7 % at 1000.
 struct Mfma16Stats {
   u32 max_tiles = 0;
   bool uniform = false;  // every image has exactly max_tiles tiles
@@ -170,7 +171,7 @@ struct Mfma16Cost {
     Mfma16Stats s;
     s.max_tiles = max_tiles;
     s.uniform = n > 0 && min_tiles == max_tiles;
-    s.prefer = n > 0 && 0.867 * q16 * (t + 400.0 * n) < 0.99 * q32 * (t + 115.0 * n);
+    s.prefer = n > 0 && 0.843 * q16 * (t + 400.0 * n) < 0.99 * q32 * (t + 115.0 * n);
     return s;
   }
 };
