@@ -10,7 +10,7 @@
 #         -fsanitize=address -I../../include ../../tests/cpp/$t.cpp -L. -lvsmatch -pthread -Wl,-rpath,'$ORIGIN' -o $t; done
 #   for t in vsm_sfm_detect vsm_sfm_match; do /opt/rocm/lib/llvm/bin/clang++ -std=c++14 -O1 -g -fsanitize=address \
 #         -I../../include ../../examples/$t.cpp -L. -lvsmatch -pthread -Wl,-rpath,'$ORIGIN' -o $t; done
-# Results: round 3 (device pool leaked on purpose, chunked batch, 16x16 scan): all nine runs clean, the two-context run exits without the CHECK below.
+# Results: round 3 (device pool leaked on purpose, chunked batch, 16x16 scan; again with the final library): all nine runs clean, the two-context run exits without the CHECK below.
 # Round 1 all four runs clean; round 2 (with the BoW database shim and the multi-context batch) all six clean,
 # and again after the batch front end (host threads) and the file-to-file tools of examples/ were added.  In the last run (two contexts) ASan's own
 # device allocator can fail a CHECK inside the HSA runtime's exit handler, after main has returned
