@@ -901,7 +901,10 @@ __global__ __launch_bounds__(256) void nominate_kernel(Job* __restrict__ jobs, u
 // per listed row one random 8-byte read (the backward result) and two table bytes instead of the six random reads of
 // the rounds before (forward result in three kernels, backward result twice): nominate + count_list + fill_list
 // 0.91 -> 0.64 ms on the real-like batch (fill_list 253 -> 27 us, count_list 390 -> 348 us).
-__global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__ jobs, u32 n_pairs,
+#ifndef COUNT_LIST_ENTRIES
+#define COUNT_LIST_ENTRIES 2
+#endif
+__global__ __launch_bounds__(256, 8) void count_list_kernel(const Job* __restrict__ jobs, u32 n_pairs,
                                                          uint2* __restrict__ scratch,
                                                          const uint2* __restrict__ flist, u32 stride,
                                                          AcceptParams prm, u32* __restrict__ counts,
@@ -920,49 +923,69 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
   // {backward result, table bytes, next entry} -> descriptors.
   // (Eight / two entries per thread with their loads issued together were measured too, before that: 379 / 360 us
   // against 348.)
+  // E entries per thread and turn (k = base + 256 e + thread), all their loads requested together: a workgroup's time is
+  // its number of turns times a chain of two round trips; measured again after the chains were shortened (E = 2 against 1).
+  constexpr u32 E = COUNT_LIST_ENTRIES;
   __shared__ uint16_t lut[260];
-  __shared__ u32 wave_cnt[4];
+  __shared__ u32 wave_cnt[E][4];
   __shared__ u32 n_tasks;
-  __shared__ u32 task_q[512], task_t[512], task_nt[512], task_key[512], task_who[512];  // who: thread << 1 | direction
-  __shared__ u32 reject[256];
+  __shared__ u32 task_q[512 * E], task_key[512 * E], task_who[512 * E];  // who: (entry of the turn) << 1 | direction
+  __shared__ u32 reject[256 * E];
   load_lut_256(lut, prm);
   const Job f = jobs[blockIdx.x], b = jobs[n_pairs + blockIdx.x];
   const uint2* list = flist + (size_t)blockIdx.x * stride;
   const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool table = gmin != nullptr;
   u32 done = 0;
-  uint2 e_next = threadIdx.x < f.pad1 ? list[threadIdx.x] : make_uint2(0u, 0u);
-  for (u32 base = 0; base < f.pad1; base += 256) {
+  uint2 e_next[E];
+#pragma unroll
+  for (u32 e = 0; e < E; e++) e_next[e] = 256 * e + threadIdx.x < f.pad1 ? list[256 * e + threadIdx.x] : make_uint2(0u, 0u);
+  for (u32 base = 0; base < f.pad1; base += 256 * E) {
     if (threadIdx.x == 0) n_tasks = 0;
-    reject[threadIdx.x] = 0;
+#pragma unroll
+    for (u32 e = 0; e < E; e++) reject[256 * e + threadIdx.x] = 0;
     __syncthreads();  // (and the accept table is there)
-    const u32 k = base + threadIdx.x;
-    const uint2 e = e_next;
-    const u32 i = e.x, j = e.y & IDX_MASK;
-    bool hit = false;
-    if (k < f.pad1) {
-      const unsigned long long raw = *reinterpret_cast<const unsigned long long*>(scratch + b.out_off + j);
-      const u32 gf = table ? (u32)gmin[f.t_off + j] : 0u, gb = table ? (u32)gmin[b.t_off + i] : 0u;
-      if (k + 256 < f.pad1) e_next = list[k + 256];
-      const uint2 vb = make_uint2((u32)raw, (u32)(raw >> 32));
-      u32 back;
-      hit = accepted(vb, lut, prm.threshold, back) && back == i;
-      const u32 df = min(e.y >> IDX_BITS, 256u), db = min(vb.x >> IDX_BITS, 256u);
-      if (hit && (refine & 1u) && !(table && gf >= (u32)lut[df] + df)) {  // second_certified, forward
-        const u32 t = atomicAdd(&n_tasks, 1u);
-        task_q[t] = f.q_off + i;
-        task_t[t] = f.t_off;
-        task_nt[t] = f.nt;
-        task_key[t] = e.y;
-        task_who[t] = threadIdx.x << 1;
+    u32 i[E], j[E], key[E], gf[E], gb[E];
+    unsigned long long raw[E];
+    bool hit[E];
+#pragma unroll
+    for (u32 e = 0; e < E; e++) {
+      const u32 k = base + 256 * e + threadIdx.x;
+      i[e] = e_next[e].x;
+      key[e] = e_next[e].y;
+      j[e] = key[e] & IDX_MASK;
+      raw[e] = 0;
+      gf[e] = gb[e] = 0;
+      if (k < f.pad1) {
+        raw[e] = *reinterpret_cast<const unsigned long long*>(scratch + b.out_off + j[e]);
+        if (table) {
+          gf[e] = gmin[f.t_off + j[e]];
+          gb[e] = gmin[b.t_off + i[e]];
+        }
+        if (k + 256 * E < f.pad1) e_next[e] = list[k + 256 * E];
       }
-      if (hit && (refine & 2u) && !(table && gb >= (u32)lut[db] + db)) {  // backward: its best is row i
-        const u32 t = atomicAdd(&n_tasks, 1u);
-        task_q[t] = b.q_off + j;
-        task_t[t] = b.t_off;
-        task_nt[t] = b.nt;
-        task_key[t] = vb.x;
-        task_who[t] = threadIdx.x << 1 | 1u;
+    }
+#pragma unroll
+    for (u32 e = 0; e < E; e++) {
+      const u32 k = base + 256 * e + threadIdx.x;
+      hit[e] = false;
+      if (k < f.pad1) {
+        const uint2 vb = make_uint2((u32)raw[e], (u32)(raw[e] >> 32));
+        u32 back;
+        hit[e] = accepted(vb, lut, prm.threshold, back) && back == i[e];
+        const u32 df = min(key[e] >> IDX_BITS, 256u), db = min(vb.x >> IDX_BITS, 256u);
+        if (hit[e] && (refine & 1u) && !(table && gf[e] >= (u32)lut[df] + df)) {  // second_certified, forward
+          const u32 t = atomicAdd(&n_tasks, 1u);
+          task_q[t] = f.q_off + i[e];
+          task_key[t] = key[e];
+          task_who[t] = (256 * e + threadIdx.x) << 1;
+        }
+        if (hit[e] && (refine & 2u) && !(table && gb[e] >= (u32)lut[db] + db)) {  // backward: its best is row i
+          const u32 t = atomicAdd(&n_tasks, 1u);
+          task_q[t] = b.q_off + j[e];
+          task_key[t] = vb.x;
+          task_who[t] = (256 * e + threadIdx.x) << 1 | 1u;
+        }
       }
     }
     __syncthreads();
@@ -971,11 +994,12 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
     // the accept test's least second best rejects the entry (the stored second best passed the test already)
     const u32 nt_ = n_tasks, team = threadIdx.x >> 3, l = threadIdx.x & 7;
     for (u32 t = team; t < nt_; t += 32) {
-      const u32 key = task_key[t], idx = key & IDX_MASK, d = key >> IDX_BITS, ntr = task_nt[t];
+      const u32 who = task_who[t], tkey = task_key[t], idx = tkey & IDX_MASK, d = tkey >> IDX_BITS;
+      const u32 t_off = (who & 1u) ? b.t_off : f.t_off, ntr = (who & 1u) ? b.nt : f.nt;
       const u32 r0 = (idx & ~31u) + (idx & 4u) + (l & 3u) + 8u * (l >> 2), r1 = r0 + 16u;
       const u32x4* dq = desc + 2 * (size_t)task_q[t];
-      const u32x4* d0 = desc + 2 * ((size_t)task_t[t] + min(r0, ntr - 1));
-      const u32x4* d1 = desc + 2 * ((size_t)task_t[t] + min(r1, ntr - 1));
+      const u32x4* d0 = desc + 2 * ((size_t)t_off + min(r0, ntr - 1));
+      const u32x4* d1 = desc + 2 * ((size_t)t_off + min(r1, ntr - 1));
       const u32x4 qa = dq[0], qb = dq[1], ta = d0[0], tb = d0[1], ua = d1[0], ub = d1[1];
       u32 dr0 = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
                 __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
@@ -986,20 +1010,27 @@ __global__ __launch_bounds__(256) void count_list_kernel(const Job* __restrict__
       u32 dr = min(dr0, dr1);
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) dr = min(dr, (u32)__shfl_xor((int)dr, o, 8));
-      if (l == 0 && dr < (u32)lut[min(d, 256u)]) reject[task_who[t] >> 1] = 1;
+      if (l == 0 && dr < (u32)lut[min(d, 256u)]) reject[who >> 1] = 1;
     }
     __syncthreads();
-    hit = hit && !reject[threadIdx.x];
-    const u64 m = __ballot(hit);
-    if (lane == 0) wave_cnt[wave] = (u32)__popcll(m);
-    __syncthreads();  // every read of this turn is through
-    u32 before = done, all = 0;
-    for (u32 w = 0; w < 4; w++) {
-      if (w < wave) before += wave_cnt[w];
-      all += wave_cnt[w];
+    u64 m[E];
+#pragma unroll
+    for (u32 e = 0; e < E; e++) {
+      hit[e] = hit[e] && !reject[256 * e + threadIdx.x];
+      m[e] = __ballot(hit[e]);
+      if (lane == 0) wave_cnt[e][wave] = (u32)__popcll(m[e]);
     }
-    if (hit) scratch[f.out_off + before + (u32)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(i, j);
-    done += all;
+    __syncthreads();  // every read of this turn is through
+#pragma unroll
+    for (u32 e = 0; e < E; e++) {  // in order: the entries e of every thread before the entries e + 1
+      u32 before = done, all = 0;
+      for (u32 w = 0; w < 4; w++) {
+        if (w < wave) before += wave_cnt[e][w];
+        all += wave_cnt[e][w];
+      }
+      if (hit[e]) scratch[f.out_off + before + (u32)__popcll(m[e] & ((1ull << lane) - 1ull))] = make_uint2(i[e], j[e]);
+      done += all;
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) counts[blockIdx.x] = done;
