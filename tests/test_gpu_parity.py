@@ -317,6 +317,58 @@ def test_the_16x16_forward_scan_at_every_tile_and_tail_boundary():
         assert np.array_equal(loose[1][int(loose[0][k]):int(loose[0][k + 1])], want), (sizes[i], sizes[j])
 
 
+def test_consumer_kernels_at_list_length_boundaries():
+    """nominate_kernel / count_list_kernel / fill_list_kernel (vsmatch_kernels.h) on pairs whose number of forward-accepted
+    rows sits on their boundaries: 256-entry passes, count_list's turns of 512 entries (two per thread), nominate's
+    2048-entry list in LDS -- K planted matches per pair of 2304-descriptor images, a third of them with a group mate
+    close enough that the group table does not certify the second best (count_list's refinement teams decide, some
+    of them against the match).  Both orientations, the pruned path on both matrix-core shapes and after a popcount
+    scan (nominate then lists from the results, not from accept bits), the unpruned path, against the oracle."""
+    n = 2304
+    counts = [0, 1, 255, 256, 257, 511, 512, 513, 767, 768, 769, 1023, 1024, 1025, 2047, 2048, 2049, 2304]
+    rng = np.random.default_rng(2024)
+    parts, pairs = [], []
+    for k_img, k in enumerate(counts):
+        a = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4)).astype(np.uint64)
+        b = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4)).astype(np.uint64)
+        rows_a = rng.choice(n, size=k, replace=False)
+        rows_b = rng.choice(n, size=k, replace=False)
+        for ra, rb in zip(rows_a.tolist(), rows_b.tolist()):
+            d = a[ra].copy()
+            for bit in rng.choice(256, size=int(rng.integers(0, 4)), replace=False).tolist():
+                d[bit >> 6] ^= np.uint64(1) << np.uint64(bit & 63)
+            b[rb] = d
+        taken = set(rows_b.tolist())
+        for t, (ra, rb) in enumerate(list(zip(rows_a.tolist(), rows_b.tolist()))[::3]):  # a group mate 0 .. 5 or 2 .. 40 bits from the copy
+            mate = rb ^ 1
+            if mate in taken or mate >= n:
+                continue
+            taken.add(mate)
+            d = b[rb].copy()
+            for bit in rng.choice(256, size=int(rng.integers(0, 6) if t & 1 else rng.integers(2, 41)), replace=False).tolist():
+                d[bit >> 6] ^= np.uint64(1) << np.uint64(bit & 63)
+            b[mate] = d
+        parts += [a, b]
+        pairs += [(2 * k_img, 2 * k_img + 1), (2 * k_img + 1, 2 * k_img)]
+    db = np.ascontiguousarray(np.concatenate(parts))
+    off = (np.arange(2 * len(counts) + 1) * n).astype(np.uint32)
+    pairs = np.array(pairs, np.uint32)
+    o = binding.port()
+    want = [o.match(db[off[i]:off[i + 1]], db[off[j]:off[j + 1]], 70, 1.2) for i, j in pairs.tolist()]
+    lens = [len(w) for w in want]
+    assert lens[0] == 0 and lens[1] == 0 and max(lens) > 1500
+    assert any(l < k for l, k in zip(lens[::2], counts))  # some planted matches fall to their close group mate
+    with vsm.Matcher(0) as mm:
+        mm.db_upload(db, off)
+        for variant in (8, M16_OFF | TILE256 | 8, POPCOUNT | 8, NO_PRUNE | 8, FLIP | M16_OFF | 8):
+            mm.set_variant(variant)
+            offs, out = mm.match_pairs(pairs, 70, 1.2)
+            if variant == 8:
+                assert mm.last_scan_kernel(0) == 3  # 2304 descriptors per image: the 16x16x128 forward scan
+            for k, w in enumerate(want):
+                assert np.array_equal(out[int(offs[k]):int(offs[k + 1])], w), (hex(variant), counts[k // 2], k & 1)
+
+
 def test_nn2_vs_oracle(m):
     for variant in (0, 8, 1, TILE64 | 8, TILE128 | 8, POPCOUNT | 8, POPCOUNT | INT_KEYS, POP_LAT | 1, FLIP | 8, FLIP | TILE64 | 8, FLIP | 1, M16 | 8):
         m.set_variant(variant)
